@@ -428,7 +428,7 @@ static int gi_solve(int n, double* J, double* z, int m, const double* N, const d
     /* step 1: most violated inactive constraint */
     double zinf = 0;
     for (int i = 0; i < n; i++) if (fabs(z[i]) > zinf) zinf = fabs(z[i]);
-    double tol = 1e-10 * (1.0 + zinf);
+    double tol = 1e-13 * (1.0 + zinf);
     int p = -1; double sp = -tol;
     for (int i = 0; i < m; i++) {
       if (active[i]) continue;

@@ -1,0 +1,54 @@
+// wbc_model.hpp -- flat 215-double model table (tools/compile_model.py) -> wbc::ModelC.
+#pragma once
+#include <math.h>
+#include "wbc_tick.hpp"
+
+namespace wbc {
+
+enum { MODEL_FLAT = 215 };
+
+// Returns 0 on success, <0 if a joint axis is not axis-aligned.
+inline int model_from_flat(const double* f, ModelC* m) {
+  int k = 0;
+  m->base_mass = f[k++];
+  double c[3];
+  for (int i = 0; i < 3; i++) c[i] = f[k++];
+  for (int i = 0; i < 3; i++) m->base_mc[i] = m->base_mass * c[i];
+  for (int i = 0; i < 6; i++) m->base_I[i] = f[k++];
+  for (int l = 0; l < 4; l++)
+    for (int j = 0; j < 3; j++) {
+      LinkC& L = m->link[l][j];
+      for (int i = 0; i < 3; i++) L.off[i] = f[k++];
+      double a[3];
+      for (int i = 0; i < 3; i++) a[i] = f[k++];
+      int ax = -1;
+      for (int i = 0; i < 3; i++)
+        if (fabs(fabs(a[i]) - 1.0) < 1e-12) ax = i;
+      if (ax < 0) return -1;
+      L.axis = ax;
+      L.sgn = a[ax] > 0 ? 1.0 : -1.0;
+      L.mass = f[k++];
+      for (int i = 0; i < 3; i++) L.mc[i] = L.mass * f[k++];
+      for (int i = 0; i < 6; i++) L.I[i] = f[k++];
+    }
+  for (int l = 0; l < 4; l++)
+    for (int i = 0; i < 3; i++) m->foot_off[l][i] = f[k++];
+  m->gravity = f[k++];
+  for (int i = 0; i < 12; i++) { m->q_perm[i] = i; m->act_perm[i] = i; }
+  return 0;
+}
+
+inline void params_default(int kind, ParamsC* p) {
+  // inverse_dynamics_controller.py:117-127 / mptc_controller.py:143-153; mu :19 / :20; Kd :93 / :115
+  if (kind == KIND_ID) {
+    p->Kp_body_p = 500.0; p->Kd_body_p = 50.0; p->Kp_body_rpy = 500.0; p->Kd_body_rpy = 50.0;
+    p->Kp_foot = 100.0; p->Kd_foot = 20.0;
+  } else {
+    p->Kp_body_p = 100.0; p->Kd_body_p = 10.0; p->Kp_body_rpy = 100.0; p->Kd_body_rpy = 10.0;
+    p->Kp_foot = 200.0; p->Kd_foot = 20.0;
+  }
+  p->w_body = 10.0; p->w_foot = 1.0; p->mu = 0.7; p->Kd_contact = 100.0;
+  p->tau_max = INFINITY; p->eps2 = 1e-8;
+}
+
+}  // namespace wbc

@@ -1,0 +1,1073 @@
+// wbc_tick.hpp -- one whole-body-QP control tick for one robot instance (product math).
+//
+// This is the arithmetic of the HIP kernels in wbc_kernels.hip: one GPU lane runs one robot
+// through wbc::tick().  It is templated on the scalar so that tools/host_tick.cpp can
+// instantiate it on the host with `double` (debugging without a GPU) and with an
+// operation-counting scalar (the frozen flops/tick figure of BASELINE.md); the shipped
+// C-ABI library (include/wbc.h) only ever runs it on the device.
+//
+// Reference path (what this replaces, per tick):
+//   controllers/basic_controller.py:101-115,173-220,246-269   M, Cv, tau_g, foot/body J, Jdv, Jd
+//   controllers/inverse_dynamics_controller.py:103-234        ID QP
+//   controllers/mptc_controller.py:125-310                    MPTC QP
+// It is NOT a translation of those dense formulas.  The quadruped's mass matrix is an
+// arrowhead (6x6 base block + four decoupled 3x3 leg blocks) and so is every operator derived
+// from it; with task coordinates y = [a_base(6); a_foot_1..4 (3 each)] (J_all is block
+// triangular with 3x3 leg Jacobians on the diagonal) the reference's 30+3nc-variable QP
+// reduces exactly to 12 variables z_l in R^3 per leg:
+//     z_l = contact force f_l          if leg l is in contact
+//     z_l = foot acceleration J_l vd   if leg l swings
+// with only the 4 nc friction rows left as inequalities (DESIGN.md "Reduced QP" derives it).
+// The QP is solved by a Goldfarb-Idnani dual active set on a QR factor of the square-root
+// form, with the same 1/2*eps2*|[tau; f]|^2 tie-break as the oracle.
+#pragma once
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define WBC_HD __host__ __device__ __forceinline__
+#define WBC_HDN __host__ __device__ __noinline__
+#else
+#define WBC_HD inline
+#define WBC_HDN
+#endif
+
+namespace wbc {
+
+enum { KIND_ID = 0, KIND_MPTC = 1 };
+enum { ST_OK = 0, ST_ITER = 1, ST_SINGULAR = 2 };
+
+struct LinkC {
+  double off[3];  // joint origin in the parent link frame
+  int axis;       // 0,1,2
+  double sgn;     // +-1
+  double mass;
+  double mc[3];   // mass * com (first moment, link frame)
+  double I[6];    // about the link origin, link frame: xx yy zz xy xz yz
+};
+struct ModelC {
+  double base_mass, base_mc[3], base_I[6];
+  LinkC link[4][3];
+  double foot_off[4][3];
+  double gravity;
+  int q_perm[12];    // canonical joint j is read from input row 7 + q_perm[j] / 6 + q_perm[j]
+  int act_perm[12];  // output row k (actuator k) = canonical joint act_perm[k]
+};
+struct ParamsC {
+  double Kp_body_p, Kd_body_p, Kp_body_rpy, Kd_body_rpy, Kp_foot, Kd_foot;
+  double w_body, w_foot, mu, Kd_contact, tau_max, eps2;
+};
+
+// ---------------------------------------------------------------- tiny vector helpers
+template <class T> WBC_HD void cross(const T* a, const T* b, T* c) {
+  T x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  c[0] = x; c[1] = y; c[2] = z;
+}
+template <class T> WBC_HD T dot(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+// y = S x for symmetric S stored [xx yy zz xy xz yz]
+template <class T> WBC_HD void symv(const T* S, const T* x, T* y) {
+  T a = S[0] * x[0] + S[3] * x[1] + S[4] * x[2];
+  T b = S[3] * x[0] + S[1] * x[1] + S[5] * x[2];
+  T c = S[4] * x[0] + S[5] * x[1] + S[2] * x[2];
+  y[0] = a; y[1] = b; y[2] = c;
+}
+// y = R x, R row-major 3x3
+template <class T> WBC_HD void rotv(const T* R, const T* x, T* y) {
+  T a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
+  T b = R[3] * x[0] + R[4] * x[1] + R[5] * x[2];
+  T c = R[6] * x[0] + R[7] * x[1] + R[8] * x[2];
+  y[0] = a; y[1] = b; y[2] = c;
+}
+// Iw = R I R' for symmetric I (6) -> symmetric (6)
+template <class T> WBC_HD void rot_inertia(const T* R, const double* I6, T* out) {
+  T I[9] = {T(I6[0]), T(I6[3]), T(I6[4]), T(I6[3]), T(I6[1]), T(I6[5]), T(I6[4]), T(I6[5]), T(I6[2])};
+  T A[9];  // A = R I
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) A[3 * i + j] = R[3 * i] * I[j] + R[3 * i + 1] * I[3 + j] + R[3 * i + 2] * I[6 + j];
+  out[0] = A[0] * R[0] + A[1] * R[1] + A[2] * R[2];
+  out[1] = A[3] * R[3] + A[4] * R[4] + A[5] * R[5];
+  out[2] = A[6] * R[6] + A[7] * R[7] + A[8] * R[8];
+  out[3] = A[0] * R[3] + A[1] * R[4] + A[2] * R[5];
+  out[4] = A[0] * R[6] + A[1] * R[7] + A[2] * R[8];
+  out[5] = A[3] * R[6] + A[4] * R[7] + A[5] * R[8];
+}
+// Shift a composite inertia (mass m, first moment h, inertia I about its origin O1) to a new
+// origin O0 with O1 = O0 + r, accumulating into (M, H, J).
+template <class T> WBC_HD void shift_add(const T& m, const T* h, const T* I, const T* r, T& M, T* H, T* J) {
+  T hr = h[0] * r[0] + h[1] * r[1] + h[2] * r[2];
+  T rr = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+  T d = T(2.0) * hr + m * rr;
+  M = M + m;
+  for (int i = 0; i < 3; i++) H[i] = H[i] + h[i] + m * r[i];
+  J[0] = J[0] + I[0] + d - (T(2.0) * h[0] * r[0] + m * r[0] * r[0]);
+  J[1] = J[1] + I[1] + d - (T(2.0) * h[1] * r[1] + m * r[1] * r[1]);
+  J[2] = J[2] + I[2] + d - (T(2.0) * h[2] * r[2] + m * r[2] * r[2]);
+  J[3] = J[3] + I[3] - (h[0] * r[1] + r[0] * h[1] + m * r[0] * r[1]);
+  J[4] = J[4] + I[4] - (h[0] * r[2] + r[0] * h[2] + m * r[0] * r[2]);
+  J[5] = J[5] + I[5] - (h[1] * r[2] + r[1] * h[2] + m * r[1] * r[2]);
+}
+
+// ---------------------------------------------------------------- per-leg data
+template <class T> struct LegKin {  // world-aligned, positions relative to the base origin
+  T r[3][3];    // link origins
+  T ax[3][3];   // joint axes
+  T mcw[3][3];  // first moments m*c in world axes
+  T Iw[3][6];   // inertia about the link origin in world axes
+  T rf[3];      // foot position
+};
+template <class T> struct LegDyn {
+  T Jl[9];    // d(foot velocity)/d(own joint rates), row-major 3x3
+  T Ji[9];    // Jl^-1
+  T Jdv[3];   // bias acceleration of the foot
+  T pd[3];    // foot velocity (world)
+  T rd[3];    // foot velocity relative to the base origin (for Jd)
+  T Jd[9];    // time derivative of Jl (MPTC, swing legs)
+  T Mbl[18];  // 6x3: rows [angular(3); linear(3)] of the base, columns own joints
+  T Mll[6];   // symmetric 3x3
+  T hl[3];    // bias + gravity on own joints
+};
+
+// Forward kinematics of one leg from cached sines/cosines.
+template <class T>
+WBC_HD void leg_fk(const ModelC& m, int l, const T* R0, const T* sn, const T* cs, LegKin<T>& K) {
+  T R[9];
+  for (int i = 0; i < 9; i++) R[i] = R0[i];
+  T p[3] = {T(0.0), T(0.0), T(0.0)};
+  for (int k = 0; k < 3; k++) {
+    const LinkC& L = m.link[l][k];
+    T off[3] = {T(L.off[0]), T(L.off[1]), T(L.off[2])}, t[3];
+    rotv(R, off, t);
+    for (int i = 0; i < 3; i++) { p[i] = p[i] + t[i]; K.r[k][i] = p[i]; }
+    int a = L.axis, b = (a + 1) % 3, c = (a + 2) % 3;
+    T s = T(L.sgn) * sn[k], co = cs[k];
+    for (int i = 0; i < 3; i++) {
+      K.ax[k][i] = T(L.sgn) * R[3 * i + a];
+      // R <- R * Rot(axis a, angle): columns b, c mix
+      T cb = R[3 * i + b], cc = R[3 * i + c];
+      R[3 * i + b] = cb * co + cc * s;
+      R[3 * i + c] = cc * co - cb * s;
+    }
+    T mc[3] = {T(L.mc[0]), T(L.mc[1]), T(L.mc[2])};
+    rotv(R, mc, K.mcw[k]);
+    rot_inertia(R, L.I, K.Iw[k]);
+  }
+  T fo[3] = {T(m.foot_off[l][0]), T(m.foot_off[l][1]), T(m.foot_off[l][2])}, t[3];
+  rotv(R, fo, t);
+  for (int i = 0; i < 3; i++) K.rf[i] = p[i] + t[i];
+}
+
+// Newton-Euler bias pass for one leg (vd = 0): joint torques hl and the leg's reaction wrench
+// (Nb about the base origin, Fb).  w0 = base angular velocity, qd = own joint rates, gz = gravity.
+// Optionally also returns the foot bias acceleration / velocities / Jd columns.
+template <class T, bool KINEXTRA>
+WBC_HD void leg_rnea(const ModelC& m, int l, const LegKin<T>& K, const T* w0, const T* qd, T gz, T* hl, T* Nb,
+                     T* Fb, LegDyn<T>* D) {
+  T w[3] = {w0[0], w0[1], w0[2]};
+  T al[3] = {T(0.0), T(0.0), T(0.0)};
+  T a[3] = {T(0.0), T(0.0), T(0.0)};   // origin acceleration minus base-origin acceleration (=0)
+  T vo[3] = {T(0.0), T(0.0), T(0.0)};  // origin velocity relative to the base origin velocity
+  T F[3][3], N[3][3];
+  const T* rp = nullptr;
+  for (int k = 0; k < 3; k++) {
+    T r[3];
+    for (int i = 0; i < 3; i++) r[i] = K.r[k][i] - (k ? rp[i] : T(0.0));
+    T wxr[3], t[3], alxr[3], wxa[3];
+    cross(w, r, wxr);
+    cross(w, wxr, t);
+    cross(al, r, alxr);
+    cross(w, K.ax[k], wxa);
+    for (int i = 0; i < 3; i++) {
+      a[i] = a[i] + alxr[i] + t[i];
+      vo[i] = vo[i] + wxr[i];
+      al[i] = al[i] + wxa[i] * qd[k];
+    }
+    if (KINEXTRA) {
+      // Jd column k = (w_parent x a_k) x (rf - r_k) + a_k x (vf - v_k); vf filled below
+      T d[3] = {K.rf[0] - K.r[k][0], K.rf[1] - K.r[k][1], K.rf[2] - K.r[k][2]}, c1[3];
+      cross(wxa, d, c1);
+      for (int i = 0; i < 3; i++) { D->Jd[3 * i + k] = c1[i]; }
+      // stash -a_k x v_k part now (v_k = vo)
+      T c2[3];
+      cross(K.ax[k], vo, c2);
+      for (int i = 0; i < 3; i++) D->Jd[3 * i + k] = D->Jd[3 * i + k] - c2[i];
+    }
+    for (int i = 0; i < 3; i++) w[i] = w[i] + K.ax[k][i] * qd[k];
+    // body wrench about the link origin
+    T ag[3] = {a[0], a[1], a[2] + gz};
+    T t1[3], t2[3], t3[3], Iw_w[3], Ial[3];
+    cross(al, K.mcw[k], t1);
+    cross(w, K.mcw[k], t2);
+    cross(w, t2, t2);
+    symv(K.Iw[k], w, Iw_w);
+    symv(K.Iw[k], al, Ial);
+    cross(w, Iw_w, t3);
+    T mk = T(m.link[l][k].mass), t4[3];
+    cross(K.mcw[k], ag, t4);
+    for (int i = 0; i < 3; i++) {
+      F[k][i] = mk * ag[i] + t1[i] + t2[i];
+      N[k][i] = Ial[i] + t3[i] + t4[i];
+    }
+    rp = K.r[k];
+  }
+  if (KINEXTRA) {
+    // foot: d = rf - r_shank
+    T d[3] = {K.rf[0] - K.r[2][0], K.rf[1] - K.r[2][1], K.rf[2] - K.r[2][2]};
+    T wxd[3], t[3], alxd[3];
+    cross(w, d, wxd);
+    cross(w, wxd, t);
+    cross(al, d, alxd);
+    for (int i = 0; i < 3; i++) {
+      D->Jdv[i] = a[i] + alxd[i] + t[i];   // + base terms added by the caller (w0 x (w0 x r) is inside a)
+      D->rd[i] = vo[i] + wxd[i];
+    }
+    for (int k = 0; k < 3; k++) {
+      T c2[3];
+      cross(K.ax[k], D->rd, c2);
+      for (int i = 0; i < 3; i++) D->Jd[3 * i + k] = D->Jd[3 * i + k] + c2[i];
+    }
+  }
+  // inward pass
+  for (int k = 2; k >= 0; k--) {
+    hl[k] = dot(K.ax[k], N[k]);
+    T r[3], rxF[3];
+    for (int i = 0; i < 3; i++) r[i] = K.r[k][i] - (k ? K.r[k - 1][i] : T(0.0));
+    cross(r, F[k], rxF);
+    if (k > 0)
+      for (int i = 0; i < 3; i++) { F[k - 1][i] = F[k - 1][i] + F[k][i]; N[k - 1][i] = N[k - 1][i] + N[k][i] + rxF[i]; }
+    else
+      for (int i = 0; i < 3; i++) { Fb[i] = F[0][i]; Nb[i] = N[0][i] + rxF[i]; }
+  }
+}
+
+// Composite-rigid-body pass for one leg: Mbl, Mll and the leg's composite inertia at the base origin.
+template <class T>
+WBC_HD void leg_crba(const ModelC& m, int l, const LegKin<T>& K, LegDyn<T>& D, T& Mc, T* Hc, T* Ic) {
+  T cm = T(0.0), ch[3] = {T(0.0), T(0.0), T(0.0)}, cI[6] = {T(0.0), T(0.0), T(0.0), T(0.0), T(0.0), T(0.0)};
+  for (int k = 2; k >= 0; k--) {
+    // composite of links k..2 about origin k
+    T zero[3] = {T(0.0), T(0.0), T(0.0)};
+    T nm = T(0.0), nh[3] = {T(0.0), T(0.0), T(0.0)}, nI[6] = {T(0.0), T(0.0), T(0.0), T(0.0), T(0.0), T(0.0)};
+    if (k < 2) {
+      T r[3] = {K.r[k + 1][0] - K.r[k][0], K.r[k + 1][1] - K.r[k][1], K.r[k + 1][2] - K.r[k][2]};
+      shift_add(cm, ch, cI, r, nm, nh, nI);
+    }
+    T mk = T(m.link[l][k].mass);
+    shift_add(mk, K.mcw[k], K.Iw[k], zero, nm, nh, nI);
+    cm = nm;
+    for (int i = 0; i < 3; i++) ch[i] = nh[i];
+    for (int i = 0; i < 6; i++) cI[i] = nI[i];
+    // unit joint acceleration of joint k: n = I a, f = a x h  (about origin k)
+    T n[3], f[3];
+    symv(cI, K.ax[k], n);
+    cross(K.ax[k], ch, f);
+    // diagonal and ancestors within the leg
+    T nk[3] = {n[0], n[1], n[2]};
+    for (int j = k; j >= 0; j--) {
+      if (j < k) {
+        T r[3] = {K.r[j + 1][0] - K.r[j][0], K.r[j + 1][1] - K.r[j][1], K.r[j + 1][2] - K.r[j][2]}, rxf[3];
+        cross(r, f, rxf);
+        for (int i = 0; i < 3; i++) nk[i] = nk[i] + rxf[i];
+      }
+      T v = dot(K.ax[j], nk);
+      // symmetric 3x3 index of (j,k), j<=k
+      int idx = (j == k) ? j : (j == 0 ? (k == 1 ? 3 : 4) : 5);
+      D.Mll[idx] = v;
+    }
+    T rxf[3];
+    cross(K.r[0], f, rxf);
+    for (int i = 0; i < 3; i++) {
+      D.Mbl[(i)*3 + k] = nk[i] + rxf[i];
+      D.Mbl[(3 + i) * 3 + k] = f[i];
+    }
+  }
+  shift_add(cm, ch, cI, K.r[0], Mc, Hc, Ic);
+}
+
+// 3x3 inverse; returns |det| relative measure
+template <class T> WBC_HD T inv3(const T* A, T* B) {
+  T c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
+  T det = A[0] * c0 + A[1] * c1 + A[2] * c2;
+  T id = T(1.0) / det;
+  B[0] = c0 * id; B[1] = (A[2] * A[7] - A[1] * A[8]) * id; B[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  B[3] = c1 * id; B[4] = (A[0] * A[8] - A[2] * A[6]) * id; B[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  B[6] = c2 * id; B[7] = (A[1] * A[6] - A[0] * A[7]) * id; B[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+  return det;
+}
+template <class T> WBC_HD void sym_to_full(const T* S, T* A) {
+  A[0] = S[0]; A[1] = S[3]; A[2] = S[4]; A[3] = S[3]; A[4] = S[1]; A[5] = S[5]; A[6] = S[4]; A[7] = S[5]; A[8] = S[2];
+}
+// C(3x3) = A(3x3) B(3x3)
+template <class T> WBC_HD void mm3(const T* A, const T* B, T* C) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+
+template <class T> WBC_HD T wabs(const T& x) { return x < T(0.0) ? T(0.0) - x : x; }
+
+// ---------------------------------------------------------------- QR + Goldfarb-Idnani (n = 12)
+enum { NZ = 12, MAXC = 40 };
+
+// Fold a block of `p` dense rows A[p][13] (12 coefficients + rhs) into the upper-triangular
+// factor R[12][13] by Householder reflections on [R_kk; A_0k..A_pk].
+template <class T> WBC_HD void qr_append(T (*R)[NZ + 1], T (*A)[NZ + 1], int p) {
+  for (int k = 0; k < NZ; k++) {
+    T s2 = T(0.0);
+    for (int i = 0; i < p; i++) s2 = s2 + A[i][k] * A[i][k];
+    if (!(s2 > T(0.0))) continue;
+    T rkk = R[k][k];
+    T nrm = sqrt(rkk * rkk + s2);
+    T alpha = (rkk > T(0.0)) ? T(0.0) - nrm : nrm;
+    T v0 = rkk - alpha;            // Householder vector [v0; A[:,k]]
+    T beta = T(1.0) / (s2 + v0 * v0) * T(2.0);
+    R[k][k] = alpha;
+    for (int j = k + 1; j <= NZ; j++) {
+      T s = v0 * R[k][j];
+      for (int i = 0; i < p; i++) s = s + A[i][k] * A[i][j];
+      s = s * beta;
+      R[k][j] = R[k][j] - s * v0;
+      for (int i = 0; i < p; i++) A[i][j] = A[i][j] - s * A[i][k];
+    }
+  }
+}
+
+// Constraint i (0..15: friction row i%4 of leg i/4; 16..39: torque box) as a unit normal over z
+// and offset: n.z >= b.
+template <class T> struct QpCons {
+  T fr[4][3];         // per contact-slot... (unused entries zero)
+  T mu_n, inv_s;      // mu / sqrt(1+mu^2), 1/sqrt(1+mu^2)
+  const T (*Trow)[NZ + 1];  // T | t0 rows for the torque box (nullable)
+  T tau_max;
+  T tnorm[12];
+  unsigned mask;
+};
+
+template <class T> WBC_HD void cons_normal(const QpCons<T>& C, int i, T* n, T& b) {
+  for (int k = 0; k < NZ; k++) n[k] = T(0.0);
+  if (i < 16) {
+    int l = i >> 2, r = i & 3;
+    // rows: +fx - mu fz <= 0, -fx - mu fz <= 0, +fy - mu fz <= 0, -fy - mu fz <= 0  ->  n.z >= 0
+    int comp = r >> 1;
+    T sg = (r & 1) ? C.inv_s : T(0.0) - C.inv_s;
+    n[3 * l + comp] = sg;
+    n[3 * l + 2] = C.mu_n;
+    b = T(0.0);
+  } else {
+    int j = (i - 16) >> 1;
+    T sg = ((i - 16) & 1) ? T(1.0) : T(-1.0);   // even: tau_j <= tau_max -> -T_j z >= t0_j - tau_max
+    T inv = T(1.0) / C.tnorm[j];
+    for (int k = 0; k < NZ; k++) n[k] = sg * C.Trow[j][k] * inv;
+    b = (T(0.0) - sg * C.Trow[j][NZ] - C.tau_max) * inv;
+  }
+}
+
+// Goldfarb-Idnani.  J = R^-1 (12x12), z = unconstrained minimiser.  `elig` = bitmask of
+// constraints that exist.  Returns status, iteration count in *iters.
+template <class T>
+WBC_HD int gi_solve(T (*J)[NZ], T* z, const QpCons<T>& C, unsigned long long elig, int* iters_out) {
+  int A[NZ], q = 0;
+  unsigned long long active = 0ull;
+  T u[NZ + 1], Rq[NZ][NZ], d[NZ], zd[NZ], r[NZ], np[NZ];
+  int iters = 0;
+  const int maxit = 200;
+  for (;;) {
+    T zinf = T(0.0);
+    for (int i = 0; i < NZ; i++) { T a = wabs(z[i]); if (a > zinf) zinf = a; }
+    T tol = T(1e-13) * (T(1.0) + zinf);
+    int p = -1;
+    T sp = T(0.0) - tol, bp = T(0.0);
+    for (int i = 0; i < MAXC; i++) {
+      if (!((elig >> i) & 1ull) || ((active >> i) & 1ull)) continue;
+      T n[NZ], b;
+      cons_normal(C, i, n, b);
+      T s = T(0.0) - b;
+      for (int k = 0; k < NZ; k++) s = s + n[k] * z[k];
+      if (s < sp) { sp = s; p = i; }
+    }
+    if (p < 0) { *iters_out = iters; return ST_OK; }
+    cons_normal(C, p, np, bp);
+    u[q] = T(0.0);
+    for (;;) {
+      if (++iters > maxit) { *iters_out = iters; return ST_ITER; }
+      T dn = T(0.0), d2n = T(0.0);
+      for (int k = 0; k < NZ; k++) {
+        T s = T(0.0);
+        for (int i = 0; i < NZ; i++) s = s + J[i][k] * np[i];
+        d[k] = s;
+        dn = dn + s * s;
+        if (k >= q) d2n = d2n + s * s;
+      }
+      for (int i = 0; i < NZ; i++) {
+        T s = T(0.0);
+        for (int k = q; k < NZ; k++) s = s + J[i][k] * d[k];
+        zd[i] = s;
+      }
+      for (int k = q - 1; k >= 0; k--) {
+        T s = d[k];
+        for (int j = k + 1; j < q; j++) s = s - Rq[k][j] * r[j];
+        r[k] = s / Rq[k][k];
+      }
+      int l = -1;
+      bool have_t1 = false;
+      T t1 = T(0.0);
+      for (int k = 0; k < q; k++)
+        if (r[k] > T(0.0)) {
+          T c = u[k] / r[k];
+          if (!have_t1 || c < t1) { t1 = c; l = k; have_t1 = true; }
+        }
+      bool dependent = !(d2n > T(1e-22) * dn) || q == NZ;
+      T t2 = T(0.0);
+      if (!dependent) {
+        T znp = T(0.0);
+        for (int i = 0; i < NZ; i++) znp = znp + zd[i] * np[i];
+        t2 = (T(0.0) - sp) / znp;
+      }
+      if (dependent && !have_t1) { *iters_out = iters; return ST_SINGULAR; }
+      bool full = !dependent && (!have_t1 || !(t1 < t2));
+      T t = full ? t2 : t1;
+      for (int k = 0; k < q; k++) u[k] = u[k] - t * r[k];
+      u[q] = u[q] + t;
+      if (!dependent)
+        for (int i = 0; i < NZ; i++) z[i] = z[i] + t * zd[i];
+      if (full) {
+        for (int j = NZ - 1; j > q; j--) {
+          T a = d[j - 1], bb = d[j];
+          if (bb == T(0.0)) continue;
+          T h = sqrt(a * a + bb * bb), c = a / h, s = bb / h;
+          d[j - 1] = h; d[j] = T(0.0);
+          for (int i = 0; i < NZ; i++) {
+            T x = J[i][j - 1], y = J[i][j];
+            J[i][j - 1] = c * x + s * y;
+            J[i][j] = c * y - s * x;
+          }
+        }
+        for (int k = 0; k <= q; k++) Rq[k][q] = d[k];
+        A[q] = p;
+        active |= (1ull << p);
+        q++;
+        break;
+      }
+      active &= ~(1ull << A[l]);
+      for (int j = l; j < q - 1; j++) {
+        A[j] = A[j + 1];
+        u[j] = u[j + 1];
+        for (int k = 0; k <= j + 1; k++) Rq[k][j] = Rq[k][j + 1];
+      }
+      u[q - 1] = u[q];
+      q--;
+      u[q + 1] = T(0.0);
+      for (int j = l; j < q; j++) {
+        T a = Rq[j][j], bb = Rq[j + 1][j];
+        if (bb == T(0.0)) continue;
+        T h = sqrt(a * a + bb * bb), c = a / h, s = bb / h;
+        for (int k = j; k < q; k++) {
+          T x = Rq[j][k], y = Rq[j + 1][k];
+          Rq[j][k] = c * x + s * y;
+          Rq[j + 1][k] = c * y - s * x;
+        }
+        for (int i = 0; i < NZ; i++) {
+          T x = J[i][j], y = J[i][j + 1];
+          J[i][j] = c * x + s * y;
+          J[i][j + 1] = c * y - s * x;
+        }
+      }
+      if (!dependent) {
+        sp = T(0.0) - bp;
+        for (int k = 0; k < NZ; k++) sp = sp + np[k] * z[k];
+      }
+    }
+  }
+}
+
+// 6x6 LU with partial pivoting, in place; piv[6].  Returns smallest |pivot| / largest |pivot|.
+template <class T> WBC_HD T lu6(T (*A)[6], int* piv) {
+  T pmin = T(0.0), pmax = T(0.0);
+  for (int c = 0; c < 6; c++) {
+    int p = c;
+    T best = wabs(A[c][c]);
+    for (int r = c + 1; r < 6; r++) { T a = wabs(A[r][c]); if (a > best) { best = a; p = r; } }
+    piv[c] = p;
+    if (p != c)
+      for (int j = 0; j < 6; j++) { T t = A[c][j]; A[c][j] = A[p][j]; A[p][j] = t; }
+    if (c == 0 || best < pmin) pmin = best;
+    if (best > pmax) pmax = best;
+    T id = T(1.0) / A[c][c];
+    for (int r = c + 1; r < 6; r++) {
+      T f = A[r][c] * id;
+      A[r][c] = f;
+      for (int j = c + 1; j < 6; j++) A[r][j] = A[r][j] - f * A[c][j];
+    }
+  }
+  return pmin / pmax;
+}
+template <class T> WBC_HD void lu6_solve(const T (*A)[6], const int* piv, T* b) {
+  for (int c = 0; c < 6; c++) {
+    if (piv[c] != c) { T t = b[c]; b[c] = b[piv[c]]; b[piv[c]] = t; }
+    for (int r = c + 1; r < 6; r++) b[r] = b[r] - A[r][c] * b[c];
+  }
+  for (int c = 5; c >= 0; c--) {
+    T s = b[c];
+    for (int j = c + 1; j < 6; j++) s = s - A[c][j] * b[j];
+    b[c] = s / A[c][c];
+  }
+}
+
+// ---------------------------------------------------------------- the tick
+// Accessors: in(i) returns input row i of this robot (q rows 0..18, v rows 19..36, targets rows
+// 37..90); outputs are written through out_tau(k, value) / out_metric(k, value).
+template <class T, int KIND, class In, class OutTau, class OutMet>
+WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T mass_scale, OutTau out_tau,
+                OutMet out_met, int* iters_out) {
+  int status = ST_OK;
+  // ---- state
+  T qw = in(0), qx = in(1), qy = in(2), qz = in(3);
+  T R0[9];
+  {
+    T s = T(2.0) / (qw * qw + qx * qx + qy * qy + qz * qz);
+    R0[0] = T(1.0) - s * (qy * qy + qz * qz); R0[1] = s * (qx * qy - qw * qz); R0[2] = s * (qx * qz + qw * qy);
+    R0[3] = s * (qx * qy + qw * qz); R0[4] = T(1.0) - s * (qx * qx + qz * qz); R0[5] = s * (qy * qz - qw * qx);
+    R0[6] = s * (qx * qz - qw * qy); R0[7] = s * (qy * qz + qw * qx); R0[8] = T(1.0) - s * (qx * qx + qy * qy);
+  }
+  T p0[3] = {in(4), in(5), in(6)};
+  T w0[3] = {in(19), in(20), in(21)};
+  T v0[3] = {in(22), in(23), in(24)};
+  T gz = T(m.gravity);
+  int nc = 0;
+  for (int l = 0; l < 4; l++) nc += (mask >> l) & 1;
+
+  LegKin<T> K[4];
+  LegDyn<T> D[4];
+  T qd[4][3];
+  // ---- base body
+  T bm = T(m.base_mass) * mass_scale;
+  T bmc_l[3] = {T(m.base_mc[0]) * mass_scale, T(m.base_mc[1]) * mass_scale, T(m.base_mc[2]) * mass_scale};
+  T bmc[3], bI[6];
+  rotv(R0, bmc_l, bmc);
+  rot_inertia(R0, m.base_I, bI);
+  for (int i = 0; i < 6; i++) bI[i] = bI[i] * mass_scale;
+  // composite inertia of the whole robot at the base origin -> Mbb; base wrench -> hb
+  T Mc = bm, Hc[3] = {bmc[0], bmc[1], bmc[2]}, Ic[6] = {bI[0], bI[1], bI[2], bI[3], bI[4], bI[5]};
+  T hb[6];
+  {
+    T t2[3], t3[3], Iw_w[3], g3[3] = {T(0.0), T(0.0), gz}, t4[3];
+    cross(w0, bmc, t2);
+    cross(w0, t2, t2);
+    symv(bI, w0, Iw_w);
+    cross(w0, Iw_w, t3);
+    cross(bmc, g3, t4);
+    for (int i = 0; i < 3; i++) { hb[i] = t3[i] + t4[i]; hb[3 + i] = bm * g3[i] + t2[i]; }
+  }
+  for (int l = 0; l < 4; l++) {
+    T sn[3], cs[3];
+    for (int k = 0; k < 3; k++) {
+      int row = m.q_perm[3 * l + k];
+      T th = in(7 + row);
+      sn[k] = sin(th); cs[k] = cos(th);
+      qd[l][k] = in(25 + row);
+    }
+    leg_fk(m, l, R0, sn, cs, K[l]);
+    T Nb[3], Fb[3];
+    leg_rnea<T, true>(m, l, K[l], w0, qd[l], gz, D[l].hl, Nb, Fb, &D[l]);
+    for (int i = 0; i < 3; i++) { hb[i] = hb[i] + Nb[i]; hb[3 + i] = hb[3 + i] + Fb[i]; }
+    leg_crba(m, l, K[l], D[l], Mc, Hc, Ic);
+    // foot Jacobian block wrt own joints
+    for (int k = 0; k < 3; k++) {
+      T d[3] = {K[l].rf[0] - K[l].r[k][0], K[l].rf[1] - K[l].r[k][1], K[l].rf[2] - K[l].r[k][2]}, c[3];
+      cross(K[l].ax[k], d, c);
+      for (int i = 0; i < 3; i++) D[l].Jl[3 * i + k] = c[i];
+    }
+    T det = inv3(D[l].Jl, D[l].Ji);
+    if (!(wabs(det) > T(1e-12))) status = ST_SINGULAR;
+    for (int i = 0; i < 3; i++) D[l].pd[i] = v0[i] + D[l].rd[i];
+  }
+  // Mbb (6x6): [[Ic, [Hc]x], [[Hc]x', Mc 1]]
+  T Gb[6][6];
+  {
+    T Mbb[6][6];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Mbb[i][j] = T(0.0);
+    Mbb[0][0] = Ic[0]; Mbb[1][1] = Ic[1]; Mbb[2][2] = Ic[2];
+    Mbb[0][1] = Mbb[1][0] = Ic[3]; Mbb[0][2] = Mbb[2][0] = Ic[4]; Mbb[1][2] = Mbb[2][1] = Ic[5];
+    Mbb[0][4] = T(0.0) - Hc[2]; Mbb[0][5] = Hc[1];
+    Mbb[1][3] = Hc[2];          Mbb[1][5] = T(0.0) - Hc[0];
+    Mbb[2][3] = T(0.0) - Hc[1]; Mbb[2][4] = Hc[0];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Mbb[3 + j][i] = Mbb[i][3 + j];
+    Mbb[3][3] = Mc; Mbb[4][4] = Mc; Mbb[5][5] = Mc;
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Gb[i][j] = Mbb[i][j];
+  }
+  // ---- task-space quantities shared by both laws (reference :156-197 / :156-257)
+  T rpy[3], E[9], Ei[9];
+  {
+    rpy[0] = atan2(R0[7], R0[8]);
+    rpy[1] = atan2(T(0.0) - R0[6], sqrt(R0[0] * R0[0] + R0[3] * R0[3]));
+    rpy[2] = atan2(R0[3], R0[0]);
+    T sp = sin(rpy[1]), cp = cos(rpy[1]), sy = sin(rpy[2]), cy = cos(rpy[2]);
+    E[0] = cp * cy; E[1] = T(0.0) - sy; E[2] = T(0.0);
+    E[3] = cp * sy; E[4] = cy;          E[5] = T(0.0);
+    E[6] = T(0.0) - sp; E[7] = T(0.0);  E[8] = T(1.0);
+    T icp = T(1.0) / cp;
+    Ei[0] = cy * icp; Ei[1] = sy * icp; Ei[2] = T(0.0);
+    Ei[3] = T(0.0) - sy; Ei[4] = cy; Ei[5] = T(0.0);
+    Ei[6] = cy * sp * icp; Ei[7] = sy * sp * icp; Ei[8] = T(1.0);
+  }
+  T rpyd[3];
+  rotv(Ei, w0, rpyd);
+  // targets
+  T tg_pb[3], tg_pdb[3], tg_pddb[3], tg_rpy[3], tg_rpyd[3], tg_rpydd[3];
+  for (int i = 0; i < 3; i++) {
+    tg_pb[i] = in(37 + i); tg_pdb[i] = in(40 + i); tg_pddb[i] = in(43 + i);
+    tg_rpy[i] = in(46 + i); tg_rpyd[i] = in(49 + i); tg_rpydd[i] = in(52 + i);
+  }
+
+  // ---- per-leg reductions: X_l = Mbl Ji, P_l = Mll Ji, Y_l = Mbl' - P_l Jfb_l, G_b, k
+  T X[4][18], Pm[4][9], Y[4][18], bc[4][3];
+  T kvec[6];
+  for (int i = 0; i < 6; i++) kvec[i] = hb[i];
+  for (int l = 0; l < 4; l++) {
+    const T* r = K[l].rf;
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 3; j++)
+        X[l][3 * i + j] = D[l].Mbl[3 * i] * D[l].Ji[j] + D[l].Mbl[3 * i + 1] * D[l].Ji[3 + j] + D[l].Mbl[3 * i + 2] * D[l].Ji[6 + j];
+    T Mf[9];
+    sym_to_full(D[l].Mll, Mf);
+    mm3(Mf, D[l].Ji, Pm[l]);
+    // Jfb = [-[r]x, 1]:  (A Jfb) = [ -A [r]x , A ];  -A[r]x column j = (A (e_j x r))... use rows: (A[r]x)_{ij}
+    // [r]x = [[0,-r2,r1],[r2,0,-r0],[-r1,r0,0]]
+    for (int i = 0; i < 6; i++) {
+      T a0 = X[l][3 * i], a1 = X[l][3 * i + 1], a2 = X[l][3 * i + 2];
+      // (X [r]x)_i = [a1 r2 - a2 r1, a2 r0 - a0 r2, a0 r1 - a1 r0]
+      Gb[i][0] = Gb[i][0] + (a1 * r[2] - a2 * r[1]);
+      Gb[i][1] = Gb[i][1] + (a2 * r[0] - a0 * r[2]);
+      Gb[i][2] = Gb[i][2] + (a0 * r[1] - a1 * r[0]);
+      Gb[i][3] = Gb[i][3] - a0; Gb[i][4] = Gb[i][4] - a1; Gb[i][5] = Gb[i][5] - a2;
+    }
+    for (int i = 0; i < 3; i++) {
+      T a0 = Pm[l][3 * i], a1 = Pm[l][3 * i + 1], a2 = Pm[l][3 * i + 2];
+      Y[l][6 * i + 0] = D[l].Mbl[0 * 3 + i] + (a1 * r[2] - a2 * r[1]);
+      Y[l][6 * i + 1] = D[l].Mbl[1 * 3 + i] + (a2 * r[0] - a0 * r[2]);
+      Y[l][6 * i + 2] = D[l].Mbl[2 * 3 + i] + (a0 * r[1] - a1 * r[0]);
+      Y[l][6 * i + 3] = D[l].Mbl[3 * 3 + i] - a0;
+      Y[l][6 * i + 4] = D[l].Mbl[4 * 3 + i] - a1;
+      Y[l][6 * i + 5] = D[l].Mbl[5 * 3 + i] - a2;
+    }
+    bool ct = (mask >> l) & 1;
+    for (int i = 0; i < 3; i++) bc[l][i] = ct ? (T(0.0) - T(P.Kd_contact) * D[l].pd[i] - D[l].Jdv[i]) : T(0.0);
+    if (ct)
+      for (int i = 0; i < 6; i++)
+        kvec[i] = kvec[i] + X[l][3 * i] * bc[l][0] + X[l][3 * i + 1] * bc[l][1] + X[l][3 * i + 2] * bc[l][2];
+  }
+  // ---- a_b = sum_l B_l z_l + ab0 with  G_b a_b = sum_ct W_l z_l - sum_sw X_l z_l - k
+  int piv[6];
+  T Gs[6][6];
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Gs[i][j] = Gb[i][j];
+  T rc = lu6(Gb, piv);
+  if (!(rc > T(1e-12))) status = ST_SINGULAR;
+  T B[6][NZ], ab0[6];
+  for (int i = 0; i < 6; i++) ab0[i] = T(0.0) - kvec[i];
+  lu6_solve(Gb, piv, ab0);
+  for (int l = 0; l < 4; l++) {
+    bool ct = (mask >> l) & 1;
+    const T* r = K[l].rf;
+    for (int j = 0; j < 3; j++) {
+      T col[6];
+      if (ct) {  // W_l e_j = [r x e_j; e_j]
+        T e[3] = {T(j == 0 ? 1.0 : 0.0), T(j == 1 ? 1.0 : 0.0), T(j == 2 ? 1.0 : 0.0)}, c[3];
+        cross(r, e, c);
+        col[0] = c[0]; col[1] = c[1]; col[2] = c[2]; col[3] = e[0]; col[4] = e[1]; col[5] = e[2];
+      } else {
+        for (int i = 0; i < 6; i++) col[i] = T(0.0) - X[l][3 * i + j];
+      }
+      lu6_solve(Gb, piv, col);
+      for (int i = 0; i < 6; i++) B[i][3 * l + j] = col[i];
+    }
+  }
+  // ---- torque map tau = Tm z + t0 (canonical joint order), rows 3l..3l+2
+  T Tm[NZ][NZ + 1];
+  for (int l = 0; l < 4; l++) {
+    bool ct = (mask >> l) & 1;
+    for (int i = 0; i < 3; i++) {
+      for (int c = 0; c < NZ; c++) {
+        T s = T(0.0);
+        for (int j = 0; j < 6; j++) s = s + Y[l][6 * i + j] * B[j][c];
+        Tm[3 * l + i][c] = s;
+      }
+      T s = D[l].hl[i];
+      for (int j = 0; j < 6; j++) s = s + Y[l][6 * i + j] * ab0[j];
+      if (ct) s = s + Pm[l][3 * i] * bc[l][0] + Pm[l][3 * i + 1] * bc[l][1] + Pm[l][3 * i + 2] * bc[l][2];
+      Tm[3 * l + i][NZ] = s;
+      for (int j = 0; j < 3; j++)
+        Tm[3 * l + i][3 * l + j] = Tm[3 * l + i][3 * l + j] + (ct ? (T(0.0) - D[l].Jl[3 * j + i]) : Pm[l][3 * i + j]);
+    }
+  }
+
+  // ---- level-1 rows into the QR factor.  R starts as the diagonal rows:
+  //      swing leg: sqrt(w_foot) (z_l - target)  [ID only];  contact leg: eps f_l
+  T eps = sqrt(T(P.eps2));
+  T Rf[NZ][NZ + 1];
+  for (int i = 0; i < NZ; i++) for (int j = 0; j <= NZ; j++) Rf[i][j] = T(0.0);
+  T blk[6][NZ + 1];
+  T met_V = T(0.0), met_err = T(0.0), met_Vdot = T(0.0);
+  // task errors (needed by both laws for logging)
+  T xt_b[6], xdt_b[6];
+  for (int i = 0; i < 3; i++) { xt_b[i] = rpy[i] - tg_rpy[i]; xt_b[3 + i] = p0[i] - tg_pb[i]; }
+  for (int i = 0; i < 6; i++) met_err = met_err + xt_b[i] * xt_b[i];
+
+  if (KIND == KIND_ID) {
+    T sw_b = sqrt(T(P.w_body)), sw_f = sqrt(T(P.w_foot));
+    // desired body acceleration (:187-195)
+    T rpydd_des[3], od[3], ades[6];
+    for (int i = 0; i < 3; i++) {
+      ades[3 + i] = tg_pddb[i] - T(P.Kp_body_p) * (p0[i] - tg_pb[i]) - T(P.Kd_body_p) * (v0[i] - tg_pdb[i]);
+      rpydd_des[i] = tg_rpydd[i] - T(P.Kp_body_rpy) * (rpy[i] - tg_rpy[i]) - T(P.Kd_body_rpy) * (rpyd[i] - tg_rpyd[i]);
+    }
+    rotv(E, rpydd_des, od);
+    for (int i = 0; i < 3; i++) ades[i] = od[i];
+    for (int l = 0; l < 4; l++) {
+      bool ct = (mask >> l) & 1;
+      for (int i = 0; i < 3; i++) {
+        if (ct) { Rf[3 * l + i][3 * l + i] = eps; continue; }
+        T pf = p0[i] + K[l].rf[i];
+        T tp = in(37 + 18 + 9 * l + i), tpd = in(37 + 21 + 9 * l + i), tpdd = in(37 + 24 + 9 * l + i);
+        T des = tpdd - T(P.Kp_foot) * (pf - tp) - T(P.Kd_foot) * (D[l].pd[i] - tpd);
+        Rf[3 * l + i][3 * l + i] = sw_f;
+        Rf[3 * l + i][NZ] = sw_f * (des - D[l].Jdv[i]);
+        met_err = met_err + (pf - tp) * (pf - tp);
+      }
+    }
+    for (int i = 0; i < 6; i++) {
+      for (int c = 0; c < NZ; c++) blk[i][c] = sw_b * B[i][c];
+      blk[i][NZ] = sw_b * (ades[i] - ab0[i]);
+    }
+    qr_append(Rf, blk, 6);
+  } else {
+    // ---------------- MPTC (mptc_controller.py:227-292), in task coordinates
+    // Task inertia (arrowhead):  Mt_bb = Gs - sum_l (Ji Jfb)' Y_l ; Mt_bl = (Ji' Y_l)' ; Mt_ll = Ji' P_l
+    T Mt_bb[6][6], Mt_bl[4][18], Mt_ll[4][9], Mli[4][9];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Mt_bb[i][j] = Gs[i][j];
+    for (int l = 0; l < 4; l++) {
+      const T* r = K[l].rf;
+      // A_l = Ji Jfb (3x6) = [ -Ji [r]x , Ji ]
+      T A[18];
+      for (int i = 0; i < 3; i++) {
+        T a0 = D[l].Ji[3 * i], a1 = D[l].Ji[3 * i + 1], a2 = D[l].Ji[3 * i + 2];
+        A[6 * i + 0] = T(0.0) - (a1 * r[2] - a2 * r[1]);
+        A[6 * i + 1] = T(0.0) - (a2 * r[0] - a0 * r[2]);
+        A[6 * i + 2] = T(0.0) - (a0 * r[1] - a1 * r[0]);
+        A[6 * i + 3] = a0; A[6 * i + 4] = a1; A[6 * i + 5] = a2;
+      }
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++)
+          Mt_bb[i][j] = Mt_bb[i][j] - (A[i] * Y[l][j] + A[6 + i] * Y[l][6 + j] + A[12 + i] * Y[l][12 + j]);
+      // Mt_lb = Ji' Y_l (3x6) ; store Mt_bl[l] as 6x3 = (Mt_lb)'
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 6; j++)
+          Mt_bl[l][3 * j + i] = D[l].Ji[i] * Y[l][j] + D[l].Ji[3 + i] * Y[l][6 + j] + D[l].Ji[6 + i] * Y[l][12 + j];
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+          Mt_ll[l][3 * i + j] = D[l].Ji[i] * Pm[l][j] + D[l].Ji[3 + i] * Pm[l][3 + j] + D[l].Ji[6 + i] * Pm[l][6 + j];
+      T Mf[9];
+      sym_to_full(D[l].Mll, Mf);
+      inv3(Mf, Mli[l]);
+    }
+    // Lambda_bb = Mt_bb - sum_ct Y_l' Mll^-1 Y_l  (contact legs eliminated)
+    T Lbb[6][6];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Lbb[i][j] = Mt_bb[i][j];
+    T MiY[4][18];  // Mll^-1 Y_l (3x6)
+    for (int l = 0; l < 4; l++) {
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 6; j++)
+          MiY[l][6 * i + j] = Mli[l][3 * i] * Y[l][j] + Mli[l][3 * i + 1] * Y[l][6 + j] + Mli[l][3 * i + 2] * Y[l][12 + j];
+      if ((mask >> l) & 1)
+        for (int i = 0; i < 6; i++)
+          for (int j = 0; j < 6; j++)
+            Lbb[i][j] = Lbb[i][j] - (Y[l][i] * MiY[l][j] + Y[l][6 + i] * MiY[l][6 + j] + Y[l][12 + i] * MiY[l][12 + j]);
+    }
+    // task errors: body (:243-257; xd uses E*rpyd = omega round trip, kept literal)
+    T om_rt[3], xdn[3], xddn[3];
+    rotv(E, rpyd, om_rt);
+    rotv(E, tg_rpyd, xdn);
+    rotv(E, tg_rpydd, xddn);
+    T xdd_b[6];
+    for (int i = 0; i < 3; i++) {
+      xdt_b[i] = om_rt[i] - xdn[i];
+      xdt_b[3 + i] = v0[i] - tg_pdb[i];
+      xdd_b[i] = xddn[i];
+      xdd_b[3 + i] = tg_pddb[i];
+    }
+    T xt_s[4][3], xdt_s[4][3], xdd_s[4][3];
+    for (int l = 0; l < 4; l++)
+      for (int i = 0; i < 3; i++) {
+        bool ct = (mask >> l) & 1;
+        T pf = p0[i] + K[l].rf[i];
+        xt_s[l][i] = ct ? T(0.0) : pf - in(37 + 18 + 9 * l + i);
+        xdt_s[l][i] = ct ? T(0.0) : D[l].pd[i] - in(37 + 21 + 9 * l + i);
+        xdd_s[l][i] = ct ? T(0.0) : in(37 + 24 + 9 * l + i);
+        met_err = met_err + xt_s[l][i] * xt_s[l][i];
+      }
+    // xi = Jbar xd_tilde in generalized coordinates: xi_b = xdt_b; foot task velocities:
+    //   swing: xdt_s ; contact: y_c = -Jl Mll^-1 Y_l xdt_b   ->  xi_l = Ji (y_l - Jfb xdt_b)
+    T xi_l[4][3];
+    for (int l = 0; l < 4; l++) {
+      const T* r = K[l].rf;
+      T jfb[3], t[3];
+      cross(xdt_b, r, t);  // omega x r
+      for (int i = 0; i < 3; i++) jfb[i] = xdt_b[3 + i] + t[i];
+      if ((mask >> l) & 1) {
+        for (int i = 0; i < 3; i++) {
+          T s = T(0.0);
+          for (int j = 0; j < 6; j++) s = s + MiY[l][6 * i + j] * xdt_b[j];
+          T s2 = D[l].Ji[3 * i] * jfb[0] + D[l].Ji[3 * i + 1] * jfb[1] + D[l].Ji[3 * i + 2] * jfb[2];
+          xi_l[l][i] = T(0.0) - s - s2;
+        }
+      } else {
+        T y[3] = {xdt_s[l][0] - jfb[0], xdt_s[l][1] - jfb[1], xdt_s[l][2] - jfb[2]};
+        rotv(D[l].Ji, y, xi_l[l]);
+      }
+    }
+    // C xi = 1/4 [h(v + xi) - h(v - xi)]  (bias is a quadratic form; gravity cancels)
+    T Cxi_b[6] = {T(0.0), T(0.0), T(0.0), T(0.0), T(0.0), T(0.0)}, Cxi_l[4][3];
+    for (int sgi = 0; sgi < 2; sgi++) {
+      T sg = sgi ? T(-1.0) : T(1.0);
+      T wv[3] = {w0[0] + sg * xdt_b[0], w0[1] + sg * xdt_b[1], w0[2] + sg * xdt_b[2]};
+      T t2[3], t3[3], Iw_w[3];
+      cross(wv, bmc, t2);
+      cross(wv, t2, t2);
+      symv(bI, wv, Iw_w);
+      cross(wv, Iw_w, t3);
+      for (int i = 0; i < 3; i++) { Cxi_b[i] = Cxi_b[i] + sg * T(0.25) * t3[i]; Cxi_b[3 + i] = Cxi_b[3 + i] + sg * T(0.25) * t2[i]; }
+      for (int l = 0; l < 4; l++) {
+        T qv[3] = {qd[l][0] + sg * xi_l[l][0], qd[l][1] + sg * xi_l[l][1], qd[l][2] + sg * xi_l[l][2]};
+        T hl2[3], Nb[3], Fb[3];
+        leg_rnea<T, false>(m, l, K[l], wv, qv, T(0.0), hl2, Nb, Fb, (LegDyn<T>*)nullptr);
+        for (int i = 0; i < 3; i++) {
+          Cxi_b[i] = Cxi_b[i] + sg * T(0.25) * Nb[i];
+          Cxi_b[3 + i] = Cxi_b[3 + i] + sg * T(0.25) * Fb[i];
+          Cxi_l[l][i] = (sgi ? Cxi_l[l][i] : T(0.0)) + sg * T(0.25) * hl2[i];
+        }
+      }
+    }
+    // g = Ybar' (C xi):  g_b = w_b - sum_l A_l' w_l ; g_l = Ji' w_l.
+    // Lambda (J Minv C xi) = g_t - [sum_ct Y_l' Mll^-1 w_l ; 0]
+    T LJMC_b[6], LJMC_s[4][3];
+    for (int i = 0; i < 6; i++) LJMC_b[i] = Cxi_b[i];
+    for (int l = 0; l < 4; l++) {
+      const T* r = K[l].rf;
+      T gl[3];  // Ji' w_l
+      for (int i = 0; i < 3; i++) gl[i] = D[l].Ji[i] * Cxi_l[l][0] + D[l].Ji[3 + i] * Cxi_l[l][1] + D[l].Ji[6 + i] * Cxi_l[l][2];
+      // A_l' w_l = Jfb' gl = [r x gl ; gl]
+      T c[3];
+      cross(r, gl, c);
+      for (int i = 0; i < 3; i++) { LJMC_b[i] = LJMC_b[i] - c[i]; LJMC_b[3 + i] = LJMC_b[3 + i] - gl[i]; }
+      if ((mask >> l) & 1) {
+        for (int j = 0; j < 6; j++)
+          LJMC_b[j] = LJMC_b[j] - (MiY[l][j] * Cxi_l[l][0] + MiY[l][6 + j] * Cxi_l[l][1] + MiY[l][12 + j] * Cxi_l[l][2]);
+        for (int i = 0; i < 3; i++) LJMC_s[l][i] = T(0.0);
+      } else {
+        for (int i = 0; i < 3; i++) LJMC_s[l][i] = gl[i];
+      }
+    }
+    // s1 = xdd_nom - Jd v + Jd xi   (task space; body rows of Jd are zero)
+    T s1_b[6], s1_s[4][3];
+    for (int i = 0; i < 6; i++) s1_b[i] = xdd_b[i];
+    for (int l = 0; l < 4; l++) {
+      if ((mask >> l) & 1) { for (int i = 0; i < 3; i++) s1_s[l][i] = T(0.0); continue; }
+      // Jd xi = xi_w x rd + Jd_l xi_l
+      T t[3];
+      cross(xdt_b, D[l].rd, t);
+      for (int i = 0; i < 3; i++) {
+        T jx = t[i] + D[l].Jd[3 * i] * xi_l[l][0] + D[l].Jd[3 * i + 1] * xi_l[l][1] + D[l].Jd[3 * i + 2] * xi_l[l][2];
+        s1_s[l][i] = xdd_s[l][i] - D[l].Jdv[i] + jx;
+      }
+    }
+    // Lambda * (vector in task space), Lambda = [[Lbb, Mt_b,sw],[Mt_sw,b, Mt_ll]]
+    auto lam_mul = [&](const T* yb, const T (*ys)[3], T* ob, T (*os)[3]) {
+      for (int i = 0; i < 6; i++) {
+        T s = T(0.0);
+        for (int j = 0; j < 6; j++) s = s + Lbb[i][j] * yb[j];
+        ob[i] = s;
+      }
+      for (int l = 0; l < 4; l++) {
+        if ((mask >> l) & 1) { os[l][0] = os[l][1] = os[l][2] = T(0.0); continue; }
+        for (int i = 0; i < 6; i++)
+          ob[i] = ob[i] + Mt_bl[l][3 * i] * ys[l][0] + Mt_bl[l][3 * i + 1] * ys[l][1] + Mt_bl[l][3 * i + 2] * ys[l][2];
+        for (int i = 0; i < 3; i++) {
+          T s = Mt_ll[l][3 * i] * ys[l][0] + Mt_ll[l][3 * i + 1] * ys[l][1] + Mt_ll[l][3 * i + 2] * ys[l][2];
+          for (int j = 0; j < 6; j++) s = s + Mt_bl[l][3 * j + i] * yb[j];
+          os[l][i] = s;
+        }
+      }
+    };
+    // c1 = -Lambda s1 + Lambda J Minv C xi + Kp xt + Kd xdt ;  residual r1(z) = Lambda y_t(z) + c1
+    T Ls_b[6], Ls_s[4][3];
+    lam_mul(s1_b, s1_s, Ls_b, Ls_s);
+    T c1_b[6], c1_s[4][3];
+    for (int i = 0; i < 6; i++) {
+      T kp = (i < 3) ? T(P.Kp_body_rpy) : T(P.Kp_body_p), kd = (i < 3) ? T(P.Kd_body_rpy) : T(P.Kd_body_p);
+      c1_b[i] = LJMC_b[i] - Ls_b[i] + kp * xt_b[i] + kd * xdt_b[i];
+      met_V = met_V + T(0.5) * kp * xt_b[i] * xt_b[i];
+      met_Vdot = met_Vdot - kd * xdt_b[i] * xdt_b[i];
+    }
+    for (int l = 0; l < 4; l++)
+      for (int i = 0; i < 3; i++) {
+        c1_s[l][i] = LJMC_s[l][i] - Ls_s[l][i] + T(P.Kp_foot) * xt_s[l][i] + T(P.Kd_foot) * xdt_s[l][i];
+        met_V = met_V + T(0.5) * T(P.Kp_foot) * xt_s[l][i] * xt_s[l][i];
+        met_Vdot = met_Vdot - T(P.Kd_foot) * xdt_s[l][i] * xdt_s[l][i];
+      }
+    {
+      T Lx_b[6], Lx_s[4][3];
+      lam_mul(xdt_b, xdt_s, Lx_b, Lx_s);
+      for (int i = 0; i < 6; i++) met_V = met_V + T(0.5) * xdt_b[i] * Lx_b[i];
+      for (int l = 0; l < 4; l++) for (int i = 0; i < 3; i++) met_V = met_V + T(0.5) * xdt_s[l][i] * Lx_s[l][i];
+    }
+    // level-1 rows: sqrt(W) (Lambda [B z + ab0; z_sw] + c1); contact legs get the eps f rows
+    T sw_b = sqrt(T(P.w_body)), sw_f = sqrt(T(P.w_foot));
+    for (int l = 0; l < 4; l++)
+      if ((mask >> l) & 1)
+        for (int i = 0; i < 3; i++) Rf[3 * l + i][3 * l + i] = eps;
+    // body rows
+    for (int i = 0; i < 6; i++) {
+      for (int c = 0; c < NZ; c++) {
+        T s = T(0.0);
+        for (int j = 0; j < 6; j++) s = s + Lbb[i][j] * B[j][c];
+        blk[i][c] = sw_b * s;
+      }
+      T s = c1_b[i];
+      for (int j = 0; j < 6; j++) s = s + Lbb[i][j] * ab0[j];
+      blk[i][NZ] = T(0.0) - sw_b * s;
+      for (int l = 0; l < 4; l++)
+        if (!((mask >> l) & 1))
+          for (int j = 0; j < 3; j++) blk[i][3 * l + j] = blk[i][3 * l + j] + sw_b * Mt_bl[l][3 * i + j];
+    }
+    qr_append(Rf, blk, 6);
+    // swing rows (3 per swing leg), appended in blocks of 3
+    for (int l = 0; l < 4; l++) {
+      if ((mask >> l) & 1) continue;
+      for (int i = 0; i < 3; i++) {
+        for (int c = 0; c < NZ; c++) {
+          T s = T(0.0);
+          for (int j = 0; j < 6; j++) s = s + Mt_bl[l][3 * j + i] * B[j][c];
+          blk[i][c] = sw_f * s;
+        }
+        T s = c1_s[l][i];
+        for (int j = 0; j < 6; j++) s = s + Mt_bl[l][3 * j + i] * ab0[j];
+        blk[i][NZ] = T(0.0) - sw_f * s;
+        for (int j = 0; j < 3; j++) blk[i][3 * l + j] = blk[i][3 * l + j] + sw_f * Mt_ll[l][3 * i + j];
+      }
+      qr_append(Rf, blk, 3);
+    }
+    // keep c1 and Lambda pieces for Vdot: Vdot = xdt' r1 - xdt' Kd xdt, r1 = Lambda y_t + c1
+    // evaluated after the solve; stash what is needed in blk-independent storage
+    // (recomputed below from z through lam_mul)
+    // -> store c1 dot xdt now:
+    for (int i = 0; i < 6; i++) met_Vdot = met_Vdot + xdt_b[i] * c1_b[i];
+    for (int l = 0; l < 4; l++) for (int i = 0; i < 3; i++) met_Vdot = met_Vdot + xdt_s[l][i] * c1_s[l][i];
+    // and Lambda xdt (symmetric) so that xdt' Lambda y_t = (Lambda xdt)' y_t
+    {
+      T Lx_b[6], Lx_s[4][3];
+      lam_mul(xdt_b, xdt_s, Lx_b, Lx_s);
+      // fold into a 12-vector over z plus constant:  y_t = [B z + ab0 ; z_sw]
+      // Vdot += Lx_b'(B z + ab0) + sum_sw Lx_s' z_l  -> coefficients kept in blk[0]
+      for (int c = 0; c < NZ; c++) {
+        T s = T(0.0);
+        for (int j = 0; j < 6; j++) s = s + Lx_b[j] * B[j][c];
+        blk[0][c] = s;
+      }
+      T s = T(0.0);
+      for (int j = 0; j < 6; j++) s = s + Lx_b[j] * ab0[j];
+      blk[0][NZ] = s;
+      for (int l = 0; l < 4; l++)
+        if (!((mask >> l) & 1))
+          for (int i = 0; i < 3; i++) blk[0][3 * l + i] = blk[0][3 * l + i] + Lx_s[l][i];
+    }
+  }
+  T vdot_row[NZ + 1];
+  for (int c = 0; c <= NZ; c++) vdot_row[c] = (KIND == KIND_MPTC) ? blk[0][c] : T(0.0);
+
+  // ---- level-2 rows: eps (Tm z + t0)
+  for (int h = 0; h < 2; h++) {
+    for (int i = 0; i < 6; i++) {
+      for (int c = 0; c < NZ; c++) blk[i][c] = eps * Tm[6 * h + i][c];
+      blk[i][NZ] = T(0.0) - eps * Tm[6 * h + i][NZ];
+    }
+    qr_append(Rf, blk, 6);
+  }
+  // ---- unconstrained minimiser and J = R^-1
+  T z[NZ], Jm[NZ][NZ];
+  {
+    T rmax = T(0.0), rmin = T(0.0);
+    for (int i = 0; i < NZ; i++) {
+      T a = wabs(Rf[i][i]);
+      if (i == 0 || a > rmax) rmax = a;
+      if (i == 0 || a < rmin) rmin = a;
+    }
+    if (!(rmin > T(1e-13) * rmax)) status = ST_SINGULAR;
+  }
+  if (status == ST_SINGULAR) {
+    for (int k = 0; k < 12; k++) out_tau(k, T(0.0));
+    out_met(0, T(0.0)); out_met(1, met_err); out_met(2, T(0.0)); out_met(3, T(0.0));
+    *iters_out = 0;
+    return status;
+  }
+  for (int k = NZ - 1; k >= 0; k--) {
+    T s = Rf[k][NZ];
+    for (int j = k + 1; j < NZ; j++) s = s - Rf[k][j] * z[j];
+    z[k] = s / Rf[k][k];
+  }
+  for (int c = 0; c < NZ; c++)
+    for (int k = NZ - 1; k >= 0; k--) {
+      if (k > c) { Jm[k][c] = T(0.0); continue; }
+      T s = (k == c) ? T(1.0) : T(0.0);
+      for (int j = k + 1; j <= c; j++) s = s - Rf[k][j] * Jm[j][c];
+      Jm[k][c] = s / Rf[k][k];
+    }
+  // ---- inequalities
+  QpCons<T> C;
+  {
+    T s = sqrt(T(1.0) + mu * mu);
+    C.inv_s = T(1.0) / s;
+    C.mu_n = mu * C.inv_s;
+    C.Trow = Tm;
+    C.tau_max = T(P.tau_max);
+    C.mask = mask;
+  }
+  unsigned long long elig = 0ull;
+  for (int l = 0; l < 4; l++)
+    if ((mask >> l) & 1) elig |= (0xFull << (4 * l));
+  if (P.tau_max < 1e300) {
+    for (int j = 0; j < 12; j++) {
+      T s = T(0.0);
+      for (int k = 0; k < NZ; k++) s = s + Tm[j][k] * Tm[j][k];
+      C.tnorm[j] = sqrt(s);
+      if (s > T(0.0)) elig |= (3ull << (16 + 2 * j));
+    }
+  }
+  int iters = 0;
+  int st = gi_solve(Jm, z, C, elig, &iters);
+  *iters_out = iters;
+  if (st != ST_OK) status = st;
+  // ---- outputs
+  T tauc[12];
+  for (int i = 0; i < 12; i++) {
+    T s = Tm[i][NZ];
+    for (int c = 0; c < NZ; c++) s = s + Tm[i][c] * z[c];
+    tauc[i] = s;
+  }
+  for (int k = 0; k < 12; k++) out_tau(k, (status == ST_SINGULAR) ? T(0.0) : tauc[m.act_perm[k]]);
+  // primal residual: worst friction / torque-box violation
+  T res = T(0.0);
+  for (int l = 0; l < 4; l++)
+    if ((mask >> l) & 1) {
+      T fx = z[3 * l], fy = z[3 * l + 1], fz = z[3 * l + 2];
+      T a = wabs(fx) - mu * fz, b = wabs(fy) - mu * fz;
+      if (a > res) res = a;
+      if (b > res) res = b;
+    }
+  if (KIND == KIND_MPTC) {
+    T s = vdot_row[NZ];
+    for (int c = 0; c < NZ; c++) s = s + vdot_row[c] * z[c];
+    met_Vdot = met_Vdot + s;
+    out_met(0, met_V); out_met(1, met_err); out_met(2, T(0.0)); out_met(3, met_Vdot);
+  } else {
+    out_met(0, T(0.0)); out_met(1, met_err); out_met(2, res); out_met(3, T(0.0));
+  }
+  return status;
+}
+
+}  // namespace wbc

@@ -1,0 +1,64 @@
+"""ctypes view of tools/libhost_tick.so: the kernel math instantiated on the host (tests only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = None
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_ROOT, "tools", "libhost_tick.so")
+        srcs = [os.path.join(_ROOT, "tools", "host_tick.cpp"),
+                os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_tick.hpp"),
+                os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_model.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                                   "-o", so, srcs[0]])
+        _LIB = C.CDLL(so)
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def run(kind, flat, q, v, targets, mask, mu=None, mass_scale=None, params12=None, q_perm=None, act_perm=None):
+    q, v, targets = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, v, targets))
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    flat = np.ascontiguousarray(flat, dtype=np.float64)
+    n = q.shape[1]
+    tau = np.zeros((12, n)); met = np.zeros((4, n)); st = np.zeros(n, np.int32); it = np.zeros(n, np.int32)
+    mu = None if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
+    ms = None if mass_scale is None else np.ascontiguousarray(mass_scale, dtype=np.float64)
+    pp = None if params12 is None else np.ascontiguousarray(params12, dtype=np.float64)
+    qp = None if q_perm is None else np.ascontiguousarray(q_perm, dtype=np.int32)
+    ap = None if act_perm is None else np.ascontiguousarray(act_perm, dtype=np.int32)
+    k = 0 if kind in (0, "id", "ID") else 1
+    rc = lib().host_tick_batch(k, _p(flat), _p(pp), qp.ctypes.data_as(_ip) if qp is not None else None,
+                               ap.ctypes.data_as(_ip) if ap is not None else None, n, n, _p(q), _p(v),
+                               _p(targets), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), _p(mu), _p(ms),
+                               _p(tau), _p(met), st.ctypes.data_as(_ip), it.ctypes.data_as(_ip))
+    assert rc == 0
+    return tau, met, st, it
+
+
+def count(kind, flat, q, v, targets, mask, mu=None, mass_scale=None):
+    q, v, targets = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, v, targets))
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    flat = np.ascontiguousarray(flat, dtype=np.float64)
+    n = q.shape[1]
+    out = np.zeros(6)
+    mu = None if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
+    ms = None if mass_scale is None else np.ascontiguousarray(mass_scale, dtype=np.float64)
+    k = 0 if kind in (0, "id", "ID") else 1
+    rc = lib().host_tick_count(k, _p(flat), None, n, n, _p(q), _p(v), _p(targets),
+                               mask.ctypes.data_as(C.POINTER(C.c_ubyte)), _p(mu), _p(ms), _p(out))
+    assert rc == 0
+    return dict(zip(["add", "mul", "div", "sqrt", "trig", "cmp"], out))

@@ -1,0 +1,186 @@
+"""Pins the oracle's QP layer: generic dense QP vs scipy, literal
+assembly identities, KKT/feasibility properties and the static-stand known answer."""
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+import energy_model as em
+from oracle import oracle_py as orc
+from quadruped_drake_amd import workloads
+
+
+def scipy_qp(Q, c, Aeq, beq, Ain, bin_, x0=None):
+    n = c.size
+    cons = []
+    if beq.size:
+        cons.append({"type": "eq", "fun": lambda x: Aeq @ x - beq, "jac": lambda x: Aeq})
+    if bin_.size:
+        cons.append({"type": "ineq", "fun": lambda x: bin_ - Ain @ x, "jac": lambda x: -Ain})
+    r = minimize(lambda x: 0.5 * x @ Q @ x + c @ x, np.zeros(n) if x0 is None else x0,
+                 jac=lambda x: Q @ x + c, constraints=cons, method="SLSQP",
+                 options={"maxiter": 1000, "ftol": 1e-15})
+    return r.x
+
+
+def test_generic_qp_vs_scipy_random():
+    rng = np.random.default_rng(0)
+    for trial in range(30):
+        n = int(rng.integers(4, 14)); me = int(rng.integers(0, 3)); mi = int(rng.integers(1, 12))
+        mls = n + 3
+        Als = rng.normal(size=(mls, n)); bls = rng.normal(size=mls)
+        Aeq = rng.normal(size=(me, n)); beq = rng.normal(size=me)
+        Ain = rng.normal(size=(mi, n)); x_feas = rng.normal(size=n)
+        if me:
+            x_feas = x_feas - np.linalg.pinv(Aeq) @ (Aeq @ x_feas - beq)
+        bin_ = Ain @ x_feas + rng.uniform(0.0, 1.0, mi)      # feasible by construction
+        dreg = np.ones(n)
+        x, st, it, res = orc.qp_solve(Als, bls, 1e-6, dreg, Aeq, beq, Ain, bin_)
+        assert st == 0
+        Q = Als.T @ Als + 1e-6 * np.eye(n); c = -Als.T @ bls
+        xs = scipy_qp(Q, c, Aeq, beq, Ain, bin_)
+        f = lambda y: 0.5 * y @ Q @ y + c @ y
+        assert res < 1e-9
+        assert f(x) <= f(xs) + 1e-9 * (1 + abs(f(xs)))
+        assert np.allclose(x, xs, atol=2e-5 * (1 + np.abs(xs).max())), (trial, np.abs(x - xs).max())
+
+
+def test_generic_qp_degenerate_active_set():
+    """4 pyramid rows on 3 variables pinned at the apex (linearly dependent active set)."""
+    mu = 0.7
+    Ain = np.array([[1, 0, -mu], [-1, 0, -mu], [0, 1, -mu], [0, -1, -mu]], float)
+    Als = np.eye(3); bls = np.array([0.3, -0.2, -5.0])    # wants fz < 0 -> apex f = 0
+    x, st, it, res = orc.qp_solve(Als, bls, 0.0, np.zeros(3), np.zeros((0, 3)), np.zeros(0), Ain, np.zeros(4))
+    assert st == 0 and np.allclose(x, 0, atol=1e-12)
+    bls = np.array([3.0, 0.0, 1.0])                       # outside the cone on +x face
+    x, st, it, res = orc.qp_solve(Als, bls, 0.0, np.zeros(3), np.zeros((0, 3)), np.zeros(0), Ain, np.zeros(4))
+    # projection onto the face x = mu z
+    nvec = np.array([1, 0, -mu]) / np.hypot(1, mu)
+    assert np.allclose(x, bls - (nvec @ bls) * nvec, atol=1e-12)
+
+
+def tick_inputs(cfg, i):
+    b = workloads.make_batch(cfg, n=max(i + 1, 8))
+    ct = [(int(b["mask"][i]) >> k) & 1 for k in range(4)]
+    return b, b["q"][:, i].copy(), b["v"][:, i].copy(), b["targets"][:, i].copy(), ct
+
+
+@pytest.mark.parametrize("kind,cfg", [("id", 2), ("mptc", 3), ("id", 3), ("mptc", 2), ("mptc", 4)])
+def test_control_law_qp_properties(kind, cfg):
+    b, q, v, tg, ct = tick_inputs(cfg, 3)
+    m = orc.model(b["model"]); p = orc.params(kind)
+    tau, met, st, qp = orc.control_law(kind, m, p, q, v, tg, ct, want_qp=True)
+    assert st == 0
+    n, nc = qp["n"], qp["nc"]
+    assert n == 30 + 3 * nc and qp["me"] == 18 + 3 * nc and qp["mi"] == 4 * nc
+    x = qp["x"]
+    # literal cost of the reference == its square-root form (up to a constant)
+    assert np.allclose(qp["Als"].T @ qp["Als"], qp["Q"], atol=1e-9 * np.abs(qp["Q"]).max())
+    assert np.allclose(-qp["Als"].T @ qp["bls"], qp["c"], atol=1e-9 * (1 + np.abs(qp["c"]).max()))
+    # feasibility: dynamics, contact, friction
+    assert np.abs(qp["Aeq"] @ x - qp["beq"]).max() < 1e-9
+    assert (qp["Ain"] @ x - qp["bin"]).max() < 1e-9
+    assert np.allclose(tau, x[18:30])
+    # A_eq has full row rank (n - rank = 12)
+    assert np.linalg.matrix_rank(qp["Aeq"]) == qp["me"]
+    # KKT of the tie-broken problem: gradient lies in the span of active constraint normals
+    eps2 = p.tiebreak_eps2
+    D = np.diag((np.arange(n) >= 18).astype(float))
+    g = qp["Q"] @ x + qp["c"] + eps2 * D @ x
+    act = np.abs(qp["Ain"] @ x - qp["bin"]) < 1e-8
+    A = np.vstack([qp["Aeq"], qp["Ain"][act]])
+    # multipliers: free for equalities, >= 0 for inequalities (active normals may be dependent
+    # at a pyramid apex, so ask for a non-negative certificate instead of the min-norm one)
+    from scipy.optimize import lsq_linear
+    lb = np.r_[np.full(qp["me"], -np.inf), np.zeros(int(act.sum()))]
+    sol = lsq_linear(A.T, -g, bounds=(lb, np.full(lb.size, np.inf)), tol=1e-14, max_iter=500)
+    assert np.abs(A.T @ sol.x + g).max() < 1e-6 * (1 + np.abs(g).max())
+
+
+@pytest.mark.parametrize("kind,cfg", [("id", 2), ("mptc", 3)])
+def test_control_law_vs_scipy(kind, cfg):
+    """Independent solve of the literal 30+3nc-variable QP with scipy SLSQP."""
+    b, q, v, tg, ct = tick_inputs(cfg, 5)
+    m = orc.model(b["model"]); p = orc.params(kind)
+    p.tiebreak_eps2 = 1e-4      # SLSQP cannot resolve 1e-8 curvature; the algorithm is the same
+    tau, met, st, qp = orc.control_law(kind, m, p, q, v, tg, ct, want_qp=True)
+    n = qp["n"]
+    D = np.diag((np.arange(n) >= 18).astype(float))
+    xs = scipy_qp(qp["Q"] + p.tiebreak_eps2 * D, qp["c"], qp["Aeq"], qp["beq"], qp["Ain"], qp["bin"], x0=qp["x"] * 0)
+    assert np.allclose(qp["x"], xs, atol=2e-5 * (1 + np.abs(xs).max())), np.abs(qp["x"] - xs).max()
+
+
+def test_tiebreak_limit_is_min_norm():
+    """eps2 -> 0: vd and the level-1 cost stop moving, |[tau; f]| is the smallest of the family."""
+    b, q, v, tg, ct = tick_inputs(2, 1)
+    m = orc.model(b["model"])
+    sols = {}
+    for e in (1e-5, 1e-8, 1e-10):
+        p = orc.params("id"); p.tiebreak_eps2 = e
+        _, _, st, qp = orc.control_law("id", m, p, q, v, tg, ct, want_qp=True)
+        assert st == 0
+        sols[e] = qp
+    x8, x10 = sols[1e-8]["x"], sols[1e-10]["x"]
+    assert np.allclose(x8[:18], x10[:18], atol=1e-6 * (1 + np.abs(x10[:18]).max()))     # vd solver-independent
+    assert np.allclose(x8[18:], x10[18:], atol=1e-5 * (1 + np.abs(x10[18:]).max()))     # tie-broken part converged
+    # any other optimal point (add an internal force in null(W)) has a larger norm
+    qp = sols[1e-8]; n = qp["n"]
+    Z = np.linalg.svd(qp["Aeq"])[2][qp["me"]:].T
+    H = Z.T @ qp["Q"] @ Z
+    w, V = np.linalg.eigh(H)
+    null = Z @ V[:, w < 1e-9 * w.max()]
+    assert null.shape[1] == 6                                   # 3nc-6 at nc=4
+    proj = null.T @ (np.diag((np.arange(n) >= 18).astype(float)) @ x10)
+    # min-norm over the free directions <=> gradient of |[tau;f]|^2 orthogonal to them, unless a cone face blocks
+    slack = qp["bin"] - qp["Ain"] @ x10
+    if slack.min() > 1e-6:
+        assert np.abs(proj).max() < 1e-4 * np.abs(x10[18:]).max()
+
+
+def test_static_stand_known_answer():
+    """q0 of simulate.py:171-176, v = 0, standing targets: vd = 0 is optimal, the feet carry the
+    weight (sum fz = m g) and tau = -Jc' f + gravity torques."""
+    q, v = workloads.nominal_state("mini_cheetah", 1)
+    q = q[:, 0]; v = v[:, 0]
+    m = orc.model("mini_cheetah")
+    tg = workloads.standing_targets("mini_cheetah", 1)[:, 0]
+    # put the body target at the actual pose so the PD term vanishes
+    tg[0:3] = q[4:7]
+    for kind in ("id", "mptc"):
+        p = orc.params(kind)
+        tau, met, st, qp = orc.control_law(kind, m, p, q, v, tg, [1, 1, 1, 1], want_qp=True)
+        assert st == 0
+        x = qp["x"]
+        assert np.abs(x[:18]).max() < 1e-5   # O(eps2) Tikhonov bias of the tie-break
+        f = x[30:].reshape(4, 3)
+        assert abs(f[:, 2].sum() - 8.252 * 9.81) < 1e-4   # same O(eps2) bias
+        assert np.abs(f[:, :2].sum(0)).max() < 1e-4
+        M, Cv, tau_g = orc.calc_dynamics(m, q, v)
+        Jc = np.vstack([orc.foot_quantities(m, q, v, i)[1] for i in range(4)])
+        assert np.allclose(tau, (tau_g - Jc.T @ f.ravel())[6:], atol=1e-5)
+        if kind == "id":
+            assert met[1] < 1e-20 or met[1] >= 0
+
+
+def test_contact_modes_0_to_4():
+    b, q, v, tg, _ = tick_inputs(3, 2)
+    m = orc.model("mini_cheetah")
+    for ct in ([0, 0, 0, 0], [1, 0, 0, 0], [0, 1, 1, 0], [1, 1, 0, 1], [1, 1, 1, 1]):
+        for kind in ("id", "mptc"):
+            tau, met, st, qp = orc.control_law(kind, m, orc.params(kind), q, v, tg, ct, want_qp=True)
+            assert st == 0, (ct, kind)
+            assert np.abs(qp["Aeq"] @ qp["x"] - qp["beq"]).max() < 1e-8
+            assert np.all(np.isfinite(tau)) and np.all(np.isfinite(met))
+
+
+def test_step_batch_matches_single_and_is_position_invariant():
+    b = workloads.make_batch(3, n=24)
+    m = orc.model("mini_cheetah"); p = orc.params("mptc")
+    tau, met, st = orc.step_batch("mptc", m, p, b["q"], b["v"], b["targets"], b["mask"], nthreads=2)
+    assert (st == 0).all()
+    for i in (0, 7, 23):
+        ct = [(int(b["mask"][i]) >> k) & 1 for k in range(4)]
+        t1, m1, s1 = orc.control_law("mptc", m, p, b["q"][:, i], b["v"][:, i], b["targets"][:, i], ct)
+        assert np.array_equal(t1, tau[:, i]) and np.array_equal(m1, met[:, i])
+    perm = np.random.default_rng(0).permutation(24)
+    tau2, _, _ = orc.step_batch("mptc", m, p, b["q"][:, perm], b["v"][:, perm], b["targets"][:, perm], b["mask"][perm])
+    assert np.array_equal(tau2, tau[:, perm])

@@ -1,0 +1,105 @@
+// host_tick.cpp -- TEST/ANALYSIS TOOL, not product code.
+// Instantiates the kernel math (quadruped_drake_amd/csrc/wbc_tick.hpp) on the host:
+//   * with `double`, so the tick arithmetic can be debugged against the oracle without a GPU;
+//   * with an operation-counting scalar, which yields the frozen flops/tick figure that
+//     bench.py's roofline uses.
+// The shipped library (libwbc_hip.so) never calls this; it has no CPU path.
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include "../quadruped_drake_amd/csrc/wbc_model.hpp"
+
+struct Cnt {  // counts[0]=add/sub, 1=mul, 2=div, 3=sqrt, 4=trig(sin/cos/atan2), 5=cmp
+  double v;
+  static thread_local uint64_t c[6];
+  Cnt() : v(0) {}
+  explicit Cnt(double x) : v(x) {}
+};
+thread_local uint64_t Cnt::c[6];
+inline Cnt operator+(const Cnt& a, const Cnt& b) { Cnt::c[0]++; return Cnt(a.v + b.v); }
+inline Cnt operator-(const Cnt& a, const Cnt& b) { Cnt::c[0]++; return Cnt(a.v - b.v); }
+inline Cnt operator*(const Cnt& a, const Cnt& b) { Cnt::c[1]++; return Cnt(a.v * b.v); }
+inline Cnt operator/(const Cnt& a, const Cnt& b) { Cnt::c[2]++; return Cnt(a.v / b.v); }
+inline bool operator<(const Cnt& a, const Cnt& b) { Cnt::c[5]++; return a.v < b.v; }
+inline bool operator>(const Cnt& a, const Cnt& b) { Cnt::c[5]++; return a.v > b.v; }
+inline bool operator==(const Cnt& a, const Cnt& b) { Cnt::c[5]++; return a.v == b.v; }
+inline Cnt sqrt(const Cnt& a) { Cnt::c[3]++; return Cnt(::sqrt(a.v)); }
+inline Cnt sin(const Cnt& a) { Cnt::c[4]++; return Cnt(::sin(a.v)); }
+inline Cnt cos(const Cnt& a) { Cnt::c[4]++; return Cnt(::cos(a.v)); }
+inline Cnt atan2(const Cnt& a, const Cnt& b) { Cnt::c[4]++; return Cnt(::atan2(a.v, b.v)); }
+
+template <class T> static double val(const T& x);
+template <> double val<double>(const double& x) { return x; }
+template <> double val<Cnt>(const Cnt& x) { return x.v; }
+
+template <class T>
+static int run_one(int kind, const wbc::ModelC& m, const wbc::ParamsC& P, int i, int stride, const double* q,
+                   const double* v, const double* tg, unsigned mask, double mu, double ms, double* tau,
+                   double* met, int* iters) {
+  auto in = [&](int r) -> T {
+    if (r < 19) return T(q[(size_t)r * stride + i]);
+    if (r < 37) return T(v[(size_t)(r - 19) * stride + i]);
+    return T(tg[(size_t)(r - 37) * stride + i]);
+  };
+  auto ot = [&](int k, T x) { tau[(size_t)k * stride + i] = val<T>(x); };
+  auto om = [&](int k, T x) { if (met) met[(size_t)k * stride + i] = val<T>(x); };
+  if (kind == wbc::KIND_ID) return wbc::tick<T, wbc::KIND_ID>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
+  return wbc::tick<T, wbc::KIND_MPTC>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
+}
+
+extern "C" {
+
+// params12: Kp_body_p, Kd_body_p, Kp_body_rpy, Kd_body_rpy, Kp_foot, Kd_foot, w_body, w_foot, mu,
+// Kd_contact, tau_max, eps2 (NULL = the reference defaults)
+int host_tick_batch(int kind, const double* flat215, const double* params12, const int* q_perm,
+                    const int* act_perm, int n, int stride, const double* q, const double* v,
+                    const double* tg, const unsigned char* mask, const double* mu, const double* mass_scale,
+                    double* tau, double* met, int* status, int* iters) {
+  wbc::ModelC m;
+  if (wbc::model_from_flat(flat215, &m)) return -1;
+  if (q_perm) for (int i = 0; i < 12; i++) m.q_perm[i] = q_perm[i];
+  if (act_perm) for (int i = 0; i < 12; i++) m.act_perm[i] = act_perm[i];
+  wbc::ParamsC P;
+  wbc::params_default(kind, &P);
+  if (params12) memcpy(&P, params12, sizeof(double) * 12);
+  for (int i = 0; i < n; i++) {
+    int it = 0;
+    int st = run_one<double>(kind, m, P, i, stride, q, v, tg, mask[i], mu ? mu[i] : P.mu,
+                             mass_scale ? mass_scale[i] : 1.0, tau, met, &it);
+    if (status) status[i] = st;
+    if (iters) iters[i] = it;
+  }
+  return 0;
+}
+
+// Mean operation counts per tick over the batch: out[6] = add, mul, div, sqrt, trig, cmp.
+int host_tick_count(int kind, const double* flat215, const double* params12, int n, int stride,
+                    const double* q, const double* v, const double* tg, const unsigned char* mask,
+                    const double* mu, const double* mass_scale, double* out6) {
+  wbc::ModelC m;
+  if (wbc::model_from_flat(flat215, &m)) return -1;
+  wbc::ParamsC P;
+  wbc::params_default(kind, &P);
+  if (params12) memcpy(&P, params12, sizeof(double) * 12);
+  for (int k = 0; k < 6; k++) Cnt::c[k] = 0;
+  double tau[12 * 1], met[4];
+  for (int i = 0; i < n; i++) {
+    int it = 0;
+    double t1[12], m1[4];
+    // write outputs to a private 1-wide scratch (stride trick: use i=0, own buffers)
+    auto in = [&](int r) -> Cnt {
+      if (r < 19) return Cnt(q[(size_t)r * stride + i]);
+      if (r < 37) return Cnt(v[(size_t)(r - 19) * stride + i]);
+      return Cnt(tg[(size_t)(r - 37) * stride + i]);
+    };
+    auto ot = [&](int k, Cnt x) { t1[k] = x.v; };
+    auto om = [&](int k, Cnt x) { m1[k] = x.v; };
+    Cnt muv(mu ? mu[i] : P.mu), msv(mass_scale ? mass_scale[i] : 1.0);
+    if (kind == wbc::KIND_ID) wbc::tick<Cnt, wbc::KIND_ID>(m, P, in, mask[i], muv, msv, ot, om, &it);
+    else wbc::tick<Cnt, wbc::KIND_MPTC>(m, P, in, mask[i], muv, msv, ot, om, &it);
+  }
+  (void)tau; (void)met;
+  for (int k = 0; k < 6; k++) out6[k] = (double)Cnt::c[k] / n;
+  return 0;
+}
+}
