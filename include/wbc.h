@@ -1,0 +1,131 @@
+/*
+ * wbc.h -- C ABI of the MI355X batched whole-body-QP controller (libwbc_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of vincekurtz/quadruped_drake: the per-control-tick
+ * whole-body QP of IDController / MPTCController.  One `wbc_step` call replaces N calls of
+ *
+ *     BasicController.DoSetControlTorques -> self.ControlLaw(context, q, v)
+ *         controllers/basic_controller.py:286-320
+ *         controllers/inverse_dynamics_controller.py:103-234   (kind = WBC_KIND_ID)
+ *         controllers/mptc_controller.py:125-310               (kind = WBC_KIND_MPTC)
+ *
+ * i.e. everything between the reference's `quad_state` / `trunk_input` input ports and its
+ * `quad_torques` / `output_metrics` output ports (basic_controller.py:33-50,
+ * inverse_dynamics_controller.py:14-16).  Plain pointers and sizes only; no torch types.
+ *
+ * Data layout: struct-of-arrays, batch index fastest.  Row r of robot i is at base[r*ld + i].
+ *   q        [19][ld]  qw qx qy qz | x y z | 12 joint angles       (simulate.py:171-176)
+ *   v        [18][ld]  w_WB (world) | v_WBo (world) | 12 joint rates (mptc_controller.py:190,194)
+ *   targets  [54][ld]  body p, pd, pdd, rpy, rpyd, rpydd (18 rows), then for each foot
+ *                      [LF RF LH RH]: p, pd, pdd (9 rows)          (planners/simple.py:45-85)
+ *   contact_mask [n]   bit i set = foot i of [LF RF LH RH] in contact (`contact_states`)
+ *   tau      [12][ld]  joint torques in ACTUATOR order             (basic_controller.py:37-40,320)
+ *   metrics  [4][ld]   V, err, res, Vdot                            (basic_controller.py:47-50,283)
+ *   status   [n]       0 optimal, 1 iteration cap, 2 singular / infeasible
+ *                      (the reference asserts result.is_success(): inverse_dynamics_controller.py:224)
+ * Joint rows of q/v are mapped through model.q_perm (canonical joint j is read from joint row
+ * q_perm[j]); torque row k is canonical joint act_perm[k]  (basic_controller.py:310-313).
+ *
+ * Error convention: every function returns 0 on success, <0 on API misuse or a HIP error;
+ * nothing throws.  wbc_last_error() returns a thread-local message.
+ * Threading: a handle is not thread-safe; distinct handles are independent (one per GPU).
+ * wbc_step is asynchronous on the handle's stream; wbc_sync blocks.  No allocation in wbc_step.
+ */
+#ifndef WBC_H
+#define WBC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WBC_KIND_ID 0
+#define WBC_KIND_MPTC 1
+
+#define WBC_MODEL_FLAT 215
+#define WBC_NQ 19
+#define WBC_NV 18
+#define WBC_NTARGET 54
+#define WBC_NU 12
+#define WBC_NMETRIC 4
+
+/* wbc_create flags */
+#define WBC_DEVICE_PTRS 0u /* wbc_step receives device pointers (default) */
+#define WBC_HOST_PTRS 1u   /* wbc_step receives host pointers; staged through handle-owned buffers */
+
+/* Kinematic tree + inertias, as produced by tools/compile_model.py from the reference's URDFs
+ * (models/mini_cheetah/mini_cheetah_mesh.urdf, models/anymal_b_simple_description/urdf/anymal_drake.urdf):
+ * flat = base{mass, com[3], I[6]}, 4 legs x 3 links {off[3], axis[3], mass, com[3], I[6]},
+ * 4 x foot_off[3], gravity.  Inertias about the link origin, order xx yy zz xy xz yz. */
+typedef struct {
+  double flat[WBC_MODEL_FLAT];
+  int32_t q_perm[12];
+  int32_t act_perm[12];
+} wbc_model;
+
+/* Gains, weights and friction: literals of the two ControlLaw bodies
+ * (inverse_dynamics_controller.py:19,93,117-127; mptc_controller.py:20,115,143-153).
+ * tau_max = +inf reproduces the reference (it has no torque rows);
+ * eps2 is the weight of the 1/2*eps2*|[tau; f]|^2 tie-break. */
+typedef struct {
+  double Kp_body_p, Kd_body_p, Kp_body_rpy, Kd_body_rpy, Kp_foot, Kd_foot;
+  double w_body, w_foot, mu, Kd_contact, tau_max, eps2;
+} wbc_params;
+
+typedef struct wbc_handle_s* wbc_handle;
+
+/* End-of-rollout statistics accumulated on the device by wbc_step (one small vector per GPU;
+ * reduced across GPUs by the host with one RCCL all-reduce). */
+typedef struct {
+  double ticks;          /* instances stepped */
+  double status_nonzero; /* instances with status != 0 */
+  double iters_sum;      /* active-set iterations */
+  double tau_abs_sum;    /* sum |tau| over all joints */
+  double tau_abs_max;    /* max |tau| */
+  double err_sum;        /* sum of metrics[1] */
+  double mask_count[16]; /* instances per contact mask */
+} wbc_stats;
+
+const char* wbc_last_error(void);
+int wbc_version(void);
+
+/* Defaults of the reference for `kind`. */
+int wbc_params_default(int kind, wbc_params* out);
+
+/* Creates a controller for up to max_batch instances on HIP device `device`.
+ * params may be NULL (reference defaults).  Owns all scratch buffers and one stream. */
+int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int max_batch, int device,
+               uint32_t flags, wbc_handle* out);
+int wbc_destroy(wbc_handle h);
+
+/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the handle's. */
+int wbc_set_stream(wbc_handle h, void* hip_stream);
+
+/* One control tick for n <= max_batch instances.  mu / mass_scale (per-instance friction
+ * coefficient and trunk mass/inertia scale; domain randomisation, no reference counterpart),
+ * metrics and status may be NULL. */
+int wbc_step(wbc_handle h, int n, int ld, const double* q, const double* v, const double* targets,
+             const uint8_t* contact_mask, const double* mu, const double* mass_scale, double* tau,
+             double* metrics, int32_t* status);
+
+int wbc_sync(wbc_handle h);
+
+/* Runs `steps` back-to-back wbc_step launches bracketed by HIP events on the handle's stream
+ * and returns the average milliseconds per launch (device time).  Blocks. */
+int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, const double* v,
+                   const double* targets, const uint8_t* contact_mask, const double* mu,
+                   const double* mass_scale, double* tau, double* metrics, int32_t* status,
+                   float* ms_per_step);
+
+/* Statistics since the last reset (blocks until the stream is idle). */
+int wbc_stats_get(wbc_handle h, wbc_stats* out);
+int wbc_stats_reset(wbc_handle h);
+
+/* Kernel resource report for the handle's kind: registers, scratch bytes/lane, LDS bytes. */
+int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

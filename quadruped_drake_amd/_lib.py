@@ -1,0 +1,73 @@
+"""ctypes binding of libwbc_hip.so (include/wbc.h).  No fallback: if the HIP library is missing or a
+call fails, this raises -- the product has no CPU path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwbc_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_u8_p = C.POINTER(C.c_uint8)
+c_i32_p = C.POINTER(C.c_int32)
+
+KIND_ID, KIND_MPTC = 0, 1
+DEVICE_PTRS, HOST_PTRS = 0, 1
+
+# every symbol include/wbc.h declares
+SYMBOLS = ["wbc_last_error", "wbc_version", "wbc_params_default", "wbc_create", "wbc_destroy", "wbc_set_stream",
+           "wbc_step", "wbc_sync", "wbc_time_steps", "wbc_stats_get", "wbc_stats_reset", "wbc_kernel_info"]
+
+
+class WbcModel(C.Structure):
+    _fields_ = [("flat", C.c_double * 215), ("q_perm", C.c_int32 * 12), ("act_perm", C.c_int32 * 12)]
+
+
+class WbcParams(C.Structure):
+    _fields_ = [(k, C.c_double) for k in
+                ("Kp_body_p", "Kd_body_p", "Kp_body_rpy", "Kd_body_rpy", "Kp_foot", "Kd_foot",
+                 "w_body", "w_foot", "mu", "Kd_contact", "tau_max", "eps2")]
+
+
+class WbcStats(C.Structure):
+    _fields_ = [("ticks", C.c_double), ("status_nonzero", C.c_double), ("iters_sum", C.c_double),
+                ("tau_abs_sum", C.c_double), ("tau_abs_max", C.c_double), ("err_sum", C.c_double),
+                ("mask_count", C.c_double * 16)]
+
+
+class WbcError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WbcError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        l.wbc_last_error.restype = C.c_char_p
+        l.wbc_version.restype = C.c_int
+        l.wbc_params_default.argtypes = [C.c_int, C.POINTER(WbcParams)]
+        l.wbc_create.argtypes = [C.POINTER(WbcModel), C.c_int, C.POINTER(WbcParams), C.c_int, C.c_int, C.c_uint32,
+                                 C.POINTER(C.c_void_p)]
+        l.wbc_destroy.argtypes = [C.c_void_p]
+        l.wbc_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        step_args = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 9
+        l.wbc_step.argtypes = step_args
+        l.wbc_sync.argtypes = [C.c_void_p]
+        l.wbc_time_steps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.POINTER(C.c_float)]
+        l.wbc_stats_get.argtypes = [C.c_void_p, C.POINTER(WbcStats)]
+        l.wbc_stats_reset.argtypes = [C.c_void_p]
+        l.wbc_kernel_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+        for s in SYMBOLS:
+            getattr(l, s)
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise WbcError("libwbc_hip: rc=%d: %s" % (rc, lib().wbc_last_error().decode()))

@@ -1,0 +1,253 @@
+"""Host-side mirror of the reference's controller interface for the whole-body-QP hot path.
+
+`IDController` / `MPTCController` keep the reference's names (controllers/inverse_dynamics_controller.py:3,
+controllers/mptc_controller.py:3) and the meaning of its ports (controllers/basic_controller.py:33-50):
+
+    quad_state   [q(19); v(18)]          -> q[19, N], v[18, N]
+    trunk_input  dict of task targets    -> targets[54, N], contact_mask[N]   (planners/simple.py:45-85)
+    quad_torques tau(12), actuator order -> tau[12, N]
+    output_metrics [V, err, res, Vdot]   -> metrics[4, N]
+
+but step a whole batch of N independent robots in one launch of the HIP kernel behind the C ABI
+(include/wbc.h).  PyTorch is used only to own device memory and the stream.  There is no CPU path.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from . import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+TRUNK_KEYS_BODY = ["p_body", "pd_body", "pdd_body", "rpy_body", "rpyd_body", "rpydd_body"]
+FEET = ["lf", "rf", "lh", "rh"]
+
+
+def load_model(name_or_path):
+    path = name_or_path if os.path.exists(name_or_path) else os.path.join(_HERE, "models", name_or_path + ".json")
+    with open(path) as f:
+        return json.load(f)
+
+
+def pack_trunk_input(trunk_data):
+    """planners/simple.py:45-85 dict -> (targets[54], contact_mask).  `f_cj`/`u2_max` are ignored,
+    exactly as ID and MPTC ignore them."""
+    t = np.zeros(54)
+    for i, k in enumerate(TRUNK_KEYS_BODY):
+        t[3 * i:3 * i + 3] = np.asarray(trunk_data[k], dtype=float).reshape(3)
+    for i, f in enumerate(FEET):
+        for j, pre in enumerate(("p_", "pd_", "pdd_")):
+            t[18 + 9 * i + 3 * j:21 + 9 * i + 3 * j] = np.asarray(trunk_data[pre + f], dtype=float).reshape(3)
+    mask = sum((1 << i) for i, c in enumerate(trunk_data["contact_states"]) if c)
+    return t, mask
+
+
+class SolverError(AssertionError):
+    """Mirrors `assert result.is_success()` (inverse_dynamics_controller.py:224)."""
+
+
+class BatchedController:
+    kind = None
+
+    def __init__(self, model="mini_cheetah", max_batch=4096, device=0, params=None, host_ptrs=False,
+                 q_perm=None, act_perm=None, use_torch_stream=True):
+        self.table = load_model(model) if isinstance(model, str) else model
+        self.max_batch = int(max_batch)
+        self.device = int(device)
+        self.host_ptrs = bool(host_ptrs)
+        L = _lib.lib()
+        m = _lib.WbcModel()
+        flat = np.asarray(self.table["flat"], dtype=np.float64)
+        assert flat.size == 215
+        m.flat[:] = flat.tolist()
+        m.q_perm[:] = list(range(12)) if q_perm is None else [int(x) for x in q_perm]
+        m.act_perm[:] = [int(x) for x in (self.table.get("act_perm", range(12)) if act_perm is None else act_perm)]
+        p = _lib.WbcParams()
+        _lib.check(L.wbc_params_default(self.kind, C.byref(p)))
+        for k, val in (params or {}).items():
+            if not hasattr(p, k):
+                raise KeyError("unknown parameter %r" % k)
+            setattr(p, k, float(val))
+        self.params = p
+        h = C.c_void_p()
+        _lib.check(L.wbc_create(C.byref(m), self.kind, C.byref(p), self.max_batch, self.device,
+                                _lib.HOST_PTRS if host_ptrs else _lib.DEVICE_PTRS, C.byref(h)))
+        self._h = h
+        self._L = L
+        if not host_ptrs and use_torch_stream:
+            import torch
+            with torch.cuda.device(self.device):
+                _lib.check(L.wbc_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.wbc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- pointers ---------------------------------------------------------------------------
+    def _ptr(self, a, rows, n, dtype, name, optional=False):
+        if a is None:
+            if optional:
+                return None, None
+            raise ValueError(name + " is required")
+        if self.host_ptrs:
+            arr = np.ascontiguousarray(a, dtype=dtype)
+            if arr.shape != ((rows, n) if rows else (n,)):
+                raise ValueError("%s: expected shape %s, got %s" % (name, (rows, n) if rows else (n,), arr.shape))
+            return arr, C.c_void_p(arr.ctypes.data)
+        import torch
+        tdt = {np.float64: torch.float64, np.uint8: torch.uint8, np.int32: torch.int32}[dtype]
+        if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == tdt and a.is_contiguous()):
+            raise ValueError("%s: expected a contiguous CUDA tensor of dtype %s" % (name, tdt))
+        if tuple(a.shape) != ((rows, n) if rows else (n,)):
+            raise ValueError("%s: expected shape %s, got %s" % (name, (rows, n) if rows else (n,), tuple(a.shape)))
+        return a, C.c_void_p(a.data_ptr())
+
+    def _out(self, rows, n, dtype):
+        if self.host_ptrs:
+            arr = np.zeros((rows, n) if rows else (n,), dtype=dtype)
+            return arr, C.c_void_p(arr.ctypes.data)
+        import torch
+        tdt = {np.float64: torch.float64, np.int32: torch.int32}[dtype]
+        t = torch.empty((rows, n) if rows else (n,), dtype=tdt, device="cuda:%d" % self.device)
+        return t, C.c_void_p(t.data_ptr())
+
+    def _args(self, q, v, targets, contact_mask, mu, mass_scale, out):
+        n = int(q.shape[1])
+        keep = []
+        ptrs = []
+        for a, rows, dt, name, opt in ((q, 19, np.float64, "q", False), (v, 18, np.float64, "v", False),
+                                       (targets, 54, np.float64, "targets", False),
+                                       (contact_mask, 0, np.uint8, "contact_mask", False),
+                                       (mu, 0, np.float64, "mu", True), (mass_scale, 0, np.float64, "mass_scale", True)):
+            k, p = self._ptr(a, rows, n, dt, name, opt)
+            keep.append(k); ptrs.append(p)
+        if out is None:
+            tau, pt = self._out(12, n, np.float64)
+            met, pm = self._out(4, n, np.float64)
+            st, ps = self._out(0, n, np.int32)
+        else:
+            tau, met, st = out
+            tau, pt = self._ptr(tau, 12, n, np.float64, "tau")
+            met, pm = self._ptr(met, 4, n, np.float64, "metrics")
+            st, ps = self._ptr(st, 0, n, np.int32, "status")
+        return n, keep, ptrs + [pt, pm, ps], (tau, met, st)
+
+    # -- the hot path -----------------------------------------------------------------------
+    def step(self, q, v, targets, contact_mask, mu=None, mass_scale=None, out=None):
+        """One control tick for the batch.  Asynchronous in device mode (call sync() or use torch)."""
+        n, keep, ptrs, outs = self._args(q, v, targets, contact_mask, mu, mass_scale, out)
+        _lib.check(self._L.wbc_step(self._h, n, n, *ptrs))
+        if self.host_ptrs:
+            self.sync()
+        self._keep = keep
+        return outs
+
+    def time_steps(self, steps, q, v, targets, contact_mask, mu=None, mass_scale=None, out=None):
+        """`steps` back-to-back launches timed with HIP events on the launch stream -> ms per launch."""
+        n, keep, ptrs, outs = self._args(q, v, targets, contact_mask, mu, mass_scale, out)
+        ms = C.c_float(0)
+        _lib.check(self._L.wbc_time_steps(self._h, int(steps), n, n, *ptrs, C.byref(ms)))
+        return ms.value, outs
+
+    def sync(self):
+        _lib.check(self._L.wbc_sync(self._h))
+
+    def stats(self, reset=False):
+        s = _lib.WbcStats()
+        _lib.check(self._L.wbc_stats_get(self._h, C.byref(s)))
+        d = dict(ticks=s.ticks, status_nonzero=s.status_nonzero, iters_sum=s.iters_sum, tau_abs_sum=s.tau_abs_sum,
+                 tau_abs_max=s.tau_abs_max, err_sum=s.err_sum, mask_count=list(s.mask_count))
+        if reset:
+            _lib.check(self._L.wbc_stats_reset(self._h))
+        return d
+
+    def kernel_info(self):
+        a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._L.wbc_kernel_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(num_regs=a.value, scratch_bytes_per_lane=b.value, lds_bytes=c.value, block_threads=d.value)
+
+    # -- single-robot convenience with the reference's signature --------------------------
+    def ControlLaw(self, q, v, trunk_data):
+        """controllers/*_controller.py ControlLaw(context, q, v) for ONE robot given the planner dict.
+        Raises SolverError on a non-zero status, like the reference's assert."""
+        t, mask = pack_trunk_input(trunk_data)
+        qq = np.asarray(q, float).reshape(19, 1); vv = np.asarray(v, float).reshape(18, 1)
+        if self.host_ptrs:
+            tau, met, st = self.step(qq, vv, t.reshape(54, 1), np.array([mask], np.uint8))
+            tau, met, st = tau[:, 0], met[:, 0], int(st[0])
+        else:
+            import torch
+            dev = "cuda:%d" % self.device
+            outs = self.step(torch.tensor(qq, device=dev), torch.tensor(vv, device=dev),
+                             torch.tensor(t.reshape(54, 1), device=dev),
+                             torch.tensor([mask], dtype=torch.uint8, device=dev))
+            self.sync()
+            tau, met, st = outs[0][:, 0].cpu().numpy(), outs[1][:, 0].cpu().numpy(), int(outs[2][0])
+        if st != 0:
+            raise SolverError("whole-body QP failed with status %d" % st)
+        self.V, self.err, self.res, self.Vdot = (float(x) for x in met)
+        return tau
+
+
+class IDController(BatchedController):
+    """controllers/inverse_dynamics_controller.py:3-234, batched."""
+    kind = _lib.KIND_ID
+
+
+class MPTCController(BatchedController):
+    """controllers/mptc_controller.py:3-310, batched."""
+    kind = _lib.KIND_MPTC
+
+
+def make_leaf_system(plant, dt, control_method="ID", model="mini_cheetah", use_lcm=False, **kw):
+    """Drop-in for `IDController(plant, dt, use_lcm)` / `MPTCController(...)` in simulate.py:106-118:
+    a pydrake LeafSystem with the reference's four ports (basic_controller.py:33-50,
+    inverse_dynamics_controller.py:14-16) that evaluates the HIP path with N = 1.
+
+    Import-guarded: pydrake is not part of this image.  The joint order of q/v and the actuator
+    order are read from the plant (they depend on the Drake release: basic_controller.py:310-313)."""
+    from pydrake.all import AbstractValue, BasicVector, LeafSystem  # noqa: guarded import
+
+    if use_lcm:
+        raise NotImplementedError("the LCM bridge of basic_controller.py:55-61,307-314 is out of scope")
+    table = load_model(model)
+    joint_names = [l["joint"] for leg in table["legs"] for l in leg["links"]]
+    q_perm = [plant.GetJointByName(nm).velocity_start() - 6 for nm in joint_names]
+    B = plant.MakeActuationMatrix()  # nv x nu
+    act_perm = [q_perm.index(int(np.argmax(B[6:, k]))) for k in range(12)]
+    cls = IDController if control_method == "ID" else MPTCController
+    ctrl = cls(model=table, max_batch=1, host_ptrs=True, q_perm=q_perm, act_perm=act_perm, **kw)
+
+    class _Leaf(LeafSystem):
+        def __init__(self):
+            LeafSystem.__init__(self)
+            self.dt = dt
+            self.ctrl = ctrl
+            self._metrics = np.zeros(4)
+            self.DeclareVectorInputPort("quad_state", BasicVector(plant.num_positions() + plant.num_velocities()))
+            self.DeclareAbstractInputPort("trunk_input", AbstractValue.Make({}))
+            self.DeclareVectorOutputPort("quad_torques", BasicVector(plant.num_actuators()), self.DoSetControlTorques)
+            self.DeclareVectorOutputPort("output_metrics", BasicVector(4), self.SetLoggingOutputs)
+
+        def DoSetControlTorques(self, context, output):
+            state = self.EvalVectorInput(context, 0).get_value()
+            q = state[:plant.num_positions()]
+            v = state[-plant.num_velocities():]
+            trunk_data = self.EvalAbstractInput(context, 1).get_value()
+            u = ctrl.ControlLaw(q, v, trunk_data)
+            self._metrics = np.array([ctrl.V, ctrl.err, ctrl.res, ctrl.Vdot])
+            output.SetFromVector(u)
+
+        def SetLoggingOutputs(self, context, output):
+            output.SetFromVector(self._metrics)
+
+    return _Leaf()

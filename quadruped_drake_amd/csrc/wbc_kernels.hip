@@ -1,0 +1,318 @@
+// wbc_kernels.hip -- HIP kernels (gfx950) + the C ABI of include/wbc.h.
+//
+// Layout in HBM: struct-of-arrays, batch index fastest, so the 64 lanes of a wavefront read
+// 64 consecutive doubles of each input row (512 B, fully coalesced).  One lane = one robot:
+// the whole tick (FK -> CRBA/RNEA -> reduced QP assembly -> QR -> active set -> torques) is a
+// single fused launch, so the only HBM traffic is the 864 algorithmic bytes per tick.
+//
+// There is no CPU path in this file: if HIP fails the entry points return an error.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/wbc.h"
+#include "wbc_model.hpp"
+#include "wbc_tick.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(const char* what, hipError_t e) {
+  snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+  return -2;
+}
+int misuse(const char* what) {
+  snprintf(g_err, sizeof g_err, "%s", what);
+  return -1;
+}
+#define HIP_TRY(x)                                  \
+  do {                                              \
+    hipError_t e_ = (x);                            \
+    if (e_ != hipSuccess) return fail(#x, e_);      \
+  } while (0)
+
+struct StatsDev {
+  double ticks, status_nonzero, iters_sum, tau_abs_sum;
+  unsigned long long tau_abs_max_bits;
+  double err_sum;
+  double mask_count[16];
+};
+
+constexpr int BLOCK = 64;
+
+__device__ __forceinline__ double wave_sum(double x) {
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+__device__ __forceinline__ double wave_max(double x) {
+  for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, 64));
+  return x;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(BLOCK)
+wbc_tick_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld,
+                const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
+                const uint8_t* __restrict__ mask, const double* __restrict__ mu,
+                const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
+                int32_t* __restrict__ status, StatsDev* __restrict__ stats) {
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  const bool live = i < n;
+  const int ii = live ? i : (n - 1);  // tail lanes recompute the last robot, stores are masked
+  const wbc::ModelC& m = *mp;
+  const wbc::ParamsC& P = *pp;
+  auto in = [&](int r) -> double {
+    if (r < 19) return q[(size_t)r * ld + ii];
+    if (r < 37) return v[(size_t)(r - 19) * ld + ii];
+    return tg[(size_t)(r - 37) * ld + ii];
+  };
+  double tsum = 0.0, tmax = 0.0, errv = 0.0;
+  auto ot = [&](int k, double x) {
+    if (live) tau[(size_t)k * ld + ii] = x;
+    tsum += fabs(x);
+    tmax = fmax(tmax, fabs(x));
+  };
+  auto om = [&](int k, double x) {
+    if (live && met) met[(size_t)k * ld + ii] = x;
+    if (k == 1) errv = x;
+  };
+  const unsigned mk = mask[ii] & 0xF;
+  const double mui = mu ? mu[ii] : P.mu;
+  const double msi = ms ? ms[ii] : 1.0;
+  int iters = 0;
+  const int st = wbc::tick<double, KIND>(m, P, in, mk, mui, msi, ot, om, &iters);
+  if (live && status) status[ii] = st;
+  if (stats) {
+    const double lv = live ? 1.0 : 0.0;
+    double a = wave_sum(lv), b = wave_sum(live && st != 0 ? 1.0 : 0.0), c = wave_sum(lv * iters);
+    double d = wave_sum(lv * tsum), e = wave_max(lv * tmax), f = wave_sum(lv * errv);
+    unsigned long long bal[16];
+    for (int k = 0; k < 16; k++) bal[k] = __ballot(live && mk == (unsigned)k);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&stats->ticks, a);
+      if (b != 0.0) atomicAdd(&stats->status_nonzero, b);
+      atomicAdd(&stats->iters_sum, c);
+      atomicAdd(&stats->tau_abs_sum, d);
+      atomicMax(&stats->tau_abs_max_bits, (unsigned long long)__double_as_longlong(e));
+      atomicAdd(&stats->err_sum, f);
+      for (int k = 0; k < 16; k++)
+        if (bal[k]) atomicAdd(&stats->mask_count[k], (double)__popcll(bal[k]));
+    }
+  }
+}
+
+}  // namespace
+
+struct wbc_handle_s {
+  int kind, max_batch, device;
+  uint32_t flags;
+  hipStream_t stream;
+  bool own_stream;
+  wbc::ModelC* d_model;
+  wbc::ParamsC* d_params;
+  StatsDev* d_stats;
+  hipEvent_t ev0, ev1;
+  // staging buffers for WBC_HOST_PTRS
+  double *s_q, *s_v, *s_tg, *s_mu, *s_ms, *s_tau, *s_met;
+  uint8_t* s_mask;
+  int32_t* s_status;
+};
+
+extern "C" {
+
+const char* wbc_last_error(void) { return g_err; }
+int wbc_version(void) { return 100; }
+
+int wbc_params_default(int kind, wbc_params* out) {
+  if (!out || (kind != WBC_KIND_ID && kind != WBC_KIND_MPTC)) return misuse("wbc_params_default: bad argument");
+  static_assert(sizeof(wbc_params) == sizeof(wbc::ParamsC), "params layout");
+  wbc::params_default(kind, reinterpret_cast<wbc::ParamsC*>(out));
+  return 0;
+}
+
+int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int max_batch, int device,
+               uint32_t flags, wbc_handle* out) {
+  if (!model || !out) return misuse("wbc_create: null argument");
+  if (kind != WBC_KIND_ID && kind != WBC_KIND_MPTC) return misuse("wbc_create: kind must be WBC_KIND_ID or WBC_KIND_MPTC");
+  if (max_batch <= 0) return misuse("wbc_create: max_batch must be positive");
+  wbc::ModelC m;
+  if (wbc::model_from_flat(model->flat, &m)) return misuse("wbc_create: joint axes must be axis-aligned");
+  bool seen_q[12] = {0}, seen_a[12] = {0};
+  for (int i = 0; i < 12; i++) {
+    int a = model->q_perm[i], b = model->act_perm[i];
+    if (a < 0 || a >= 12 || b < 0 || b >= 12 || seen_q[a] || seen_a[b]) return misuse("wbc_create: q_perm/act_perm must be permutations of 0..11");
+    seen_q[a] = seen_a[b] = true;
+    m.q_perm[i] = a;
+    m.act_perm[i] = b;
+  }
+  wbc::ParamsC P;
+  wbc::params_default(kind, &P);
+  if (params) memcpy(&P, params, sizeof P);
+  if (!(P.mu > 0) || !(P.eps2 > 0) || !(P.w_body > 0) || !(P.w_foot > 0) || !(P.tau_max > 0))
+    return misuse("wbc_create: mu, eps2, w_body, w_foot and tau_max must be positive");
+  HIP_TRY(hipSetDevice(device));
+  wbc_handle h = new wbc_handle_s();
+  memset(h, 0, sizeof *h);
+  h->kind = kind; h->max_batch = max_batch; h->device = device; h->flags = flags;
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  h->own_stream = true;
+  HIP_TRY(hipMalloc(&h->d_model, sizeof m));
+  HIP_TRY(hipMalloc(&h->d_params, sizeof P));
+  HIP_TRY(hipMalloc(&h->d_stats, sizeof(StatsDev)));
+  HIP_TRY(hipMemcpy(h->d_model, &m, sizeof m, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->d_params, &P, sizeof P, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(h->d_stats, 0, sizeof(StatsDev)));
+  HIP_TRY(hipEventCreate(&h->ev0));
+  HIP_TRY(hipEventCreate(&h->ev1));
+  if (flags & WBC_HOST_PTRS) {
+    size_t nb = (size_t)max_batch;
+    HIP_TRY(hipMalloc(&h->s_q, 19 * nb * 8)); HIP_TRY(hipMalloc(&h->s_v, 18 * nb * 8));
+    HIP_TRY(hipMalloc(&h->s_tg, 54 * nb * 8)); HIP_TRY(hipMalloc(&h->s_mu, nb * 8));
+    HIP_TRY(hipMalloc(&h->s_ms, nb * 8)); HIP_TRY(hipMalloc(&h->s_tau, 12 * nb * 8));
+    HIP_TRY(hipMalloc(&h->s_met, 4 * nb * 8)); HIP_TRY(hipMalloc(&h->s_mask, nb));
+    HIP_TRY(hipMalloc(&h->s_status, nb * 4));
+  }
+  *out = h;
+  return 0;
+}
+
+int wbc_destroy(wbc_handle h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  void* bufs[] = {h->d_model, h->d_params, h->d_stats, h->s_q, h->s_v, h->s_tg, h->s_mu, h->s_ms,
+                  h->s_tau, h->s_met, h->s_mask, h->s_status};
+  for (void* b : bufs) (void)hipFree(b);
+  (void)hipEventDestroy(h->ev0);
+  (void)hipEventDestroy(h->ev1);
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return 0;
+}
+
+int wbc_set_stream(wbc_handle h, void* hip_stream) {
+  if (!h) return misuse("wbc_set_stream: null handle");
+  if (h->own_stream) {
+    (void)hipStreamSynchronize(h->stream);
+    (void)hipStreamDestroy(h->stream);
+  }
+  h->stream = (hipStream_t)hip_stream;
+  h->own_stream = false;
+  return 0;
+}
+
+static int launch(wbc_handle h, int n, int ld, const double* q, const double* v, const double* tg,
+                  const uint8_t* mask, const double* mu, const double* ms, double* tau, double* met,
+                  int32_t* status) {
+  dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
+  if (h->kind == WBC_KIND_ID)
+    hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_ID>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q,
+                       v, tg, mask, mu, ms, tau, met, status, h->d_stats);
+  else
+    hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_MPTC>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld,
+                       q, v, tg, mask, mu, ms, tau, met, status, h->d_stats);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int check_step_args(wbc_handle h, int n, int ld, const void* q, const void* v, const void* tg,
+                           const void* mask, const void* tau) {
+  if (!h) return misuse("wbc_step: null handle");
+  if (n < 0 || n > h->max_batch) return misuse("wbc_step: n out of range (0..max_batch)");
+  if (n > 0 && ld < n) return misuse("wbc_step: ld must be >= n");
+  if (n > 0 && (!q || !v || !tg || !mask || !tau)) return misuse("wbc_step: q, v, targets, contact_mask and tau are required");
+  return 0;
+}
+
+int wbc_step(wbc_handle h, int n, int ld, const double* q, const double* v, const double* targets,
+             const uint8_t* contact_mask, const double* mu, const double* mass_scale, double* tau,
+             double* metrics, int32_t* status) {
+  int rc = check_step_args(h, n, ld, q, v, targets, contact_mask, tau);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(h->device));
+  if (!(h->flags & WBC_HOST_PTRS))
+    return launch(h, n, ld, q, v, targets, contact_mask, mu, mass_scale, tau, metrics, status);
+  // host pointers: stage rows through the handle's device buffers (leading dimension n on the device)
+  hipStream_t s = h->stream;
+  HIP_TRY(hipMemcpy2DAsync(h->s_q, (size_t)n * 8, q, (size_t)ld * 8, (size_t)n * 8, 19, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpy2DAsync(h->s_v, (size_t)n * 8, v, (size_t)ld * 8, (size_t)n * 8, 18, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpy2DAsync(h->s_tg, (size_t)n * 8, targets, (size_t)ld * 8, (size_t)n * 8, 54, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(h->s_mask, contact_mask, n, hipMemcpyHostToDevice, s));
+  if (mu) HIP_TRY(hipMemcpyAsync(h->s_mu, mu, (size_t)n * 8, hipMemcpyHostToDevice, s));
+  if (mass_scale) HIP_TRY(hipMemcpyAsync(h->s_ms, mass_scale, (size_t)n * 8, hipMemcpyHostToDevice, s));
+  rc = launch(h, n, n, h->s_q, h->s_v, h->s_tg, h->s_mask, mu ? h->s_mu : nullptr, mass_scale ? h->s_ms : nullptr,
+              h->s_tau, metrics ? h->s_met : nullptr, status ? h->s_status : nullptr);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpy2DAsync(tau, (size_t)ld * 8, h->s_tau, (size_t)n * 8, (size_t)n * 8, 12, hipMemcpyDeviceToHost, s));
+  if (metrics) HIP_TRY(hipMemcpy2DAsync(metrics, (size_t)ld * 8, h->s_met, (size_t)n * 8, (size_t)n * 8, 4, hipMemcpyDeviceToHost, s));
+  if (status) HIP_TRY(hipMemcpyAsync(status, h->s_status, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+int wbc_sync(wbc_handle h) {
+  if (!h) return misuse("wbc_sync: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, const double* v,
+                   const double* targets, const uint8_t* contact_mask, const double* mu,
+                   const double* mass_scale, double* tau, double* metrics, int32_t* status,
+                   float* ms_per_step) {
+  int rc = check_step_args(h, n, ld, q, v, targets, contact_mask, tau);
+  if (rc) return rc;
+  if (steps <= 0 || !ms_per_step) return misuse("wbc_time_steps: steps must be positive and ms_per_step non-null");
+  if (h->flags & WBC_HOST_PTRS) return misuse("wbc_time_steps: needs a WBC_DEVICE_PTRS handle (inputs resident in HBM)");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipEventRecord(h->ev0, h->stream));
+  for (int s = 0; s < steps; s++) {
+    rc = launch(h, n, ld, q, v, targets, contact_mask, mu, mass_scale, tau, metrics, status);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *ms_per_step = ms / steps;
+  return 0;
+}
+
+int wbc_stats_get(wbc_handle h, wbc_stats* out) {
+  if (!h || !out) return misuse("wbc_stats_get: null argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  StatsDev s;
+  HIP_TRY(hipMemcpy(&s, h->d_stats, sizeof s, hipMemcpyDeviceToHost));
+  out->ticks = s.ticks; out->status_nonzero = s.status_nonzero; out->iters_sum = s.iters_sum;
+  out->tau_abs_sum = s.tau_abs_sum; out->err_sum = s.err_sum;
+  double mx; memcpy(&mx, &s.tau_abs_max_bits, 8);
+  out->tau_abs_max = mx;
+  for (int k = 0; k < 16; k++) out->mask_count[k] = s.mask_count[k];
+  return 0;
+}
+
+int wbc_stats_reset(wbc_handle h) {
+  if (!h) return misuse("wbc_stats_reset: null handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipMemsetAsync(h->d_stats, 0, sizeof(StatsDev), h->stream));
+  return 0;
+}
+
+int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads) {
+  if (!h) return misuse("wbc_kernel_info: null handle");
+  hipFuncAttributes a;
+  if (h->kind == WBC_KIND_ID) HIP_TRY(hipFuncGetAttributes(&a, (const void*)wbc_tick_kernel<wbc::KIND_ID>));
+  else HIP_TRY(hipFuncGetAttributes(&a, (const void*)wbc_tick_kernel<wbc::KIND_MPTC>));
+  if (num_vgpr) *num_vgpr = a.numRegs;
+  if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;
+  if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;
+  if (block_threads) *block_threads = BLOCK;
+  return 0;
+}
+
+}  // extern "C"

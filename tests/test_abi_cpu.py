@@ -1,0 +1,95 @@
+"""CPU-side checks of the C-ABI library and the host logic (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from quadruped_drake_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    l = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "wbc.h")).read()
+    declared = sorted(set(re.findall(r"\b(wbc_[a-z_]+)\s*\(", hdr)))
+    assert declared == sorted(_lib.SYMBOLS), (declared, sorted(_lib.SYMBOLS))
+    for s in declared:
+        assert hasattr(l, s), s
+    assert l.wbc_version() >= 100
+
+
+def test_params_default_matches_reference_literals():
+    from quadruped_drake_amd import _lib
+    l = _lib.lib()
+    p = _lib.WbcParams()
+    assert l.wbc_params_default(0, C.byref(p)) == 0
+    # inverse_dynamics_controller.py:117-127, :19, :93
+    assert (p.Kp_body_p, p.Kd_body_p, p.Kp_foot, p.Kd_foot, p.w_body, p.w_foot, p.mu, p.Kd_contact) == \
+        (500.0, 50.0, 100.0, 20.0, 10.0, 1.0, 0.7, 100.0)
+    assert l.wbc_params_default(1, C.byref(p)) == 0
+    # mptc_controller.py:143-153
+    assert (p.Kp_body_p, p.Kd_body_p, p.Kp_foot, p.Kd_foot, p.w_body, p.w_foot, p.mu) == (100.0, 10.0, 200.0, 20.0, 10.0, 1.0, 0.7)
+    assert np.isinf(p.tau_max)
+    assert l.wbc_params_default(7, C.byref(p)) < 0
+    assert b"bad argument" in l.wbc_last_error()
+
+
+def test_create_rejects_misuse_and_fails_loudly_without_gpu():
+    import torch
+    from quadruped_drake_amd import _lib, IDController
+    l = _lib.lib()
+    h = C.c_void_p()
+    m = _lib.WbcModel()
+    assert l.wbc_create(None, 0, None, 8, 0, 0, C.byref(h)) < 0
+    from quadruped_drake_amd.controller import load_model
+    m.flat[:] = load_model("mini_cheetah")["flat"]
+    m.q_perm[:] = list(range(12)); m.act_perm[:] = list(range(12))
+    assert l.wbc_create(C.byref(m), 5, None, 8, 0, 0, C.byref(h)) < 0        # bad kind
+    assert l.wbc_create(C.byref(m), 0, None, 0, 0, 0, C.byref(h)) < 0        # bad batch
+    m.q_perm[3] = 4
+    assert l.wbc_create(C.byref(m), 0, None, 8, 0, 0, C.byref(h)) < 0        # not a permutation
+    assert b"permutation" in l.wbc_last_error()
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.WbcError):
+            IDController(max_batch=4, host_ptrs=True)       # no CPU fallback: must raise
+
+
+def test_pack_trunk_input_follows_planner_schema():
+    """planners/simple.py:45-85 dict -> 54 rows + mask."""
+    from quadruped_drake_amd import pack_trunk_input
+    d = {"p_lf": [0.175, 0.11, 0], "p_rf": [0.175, -0.11, 0], "p_lh": [-0.2, 0.11, 0], "p_rh": [-0.2, -0.11, 0]}
+    for f in ("lf", "rf", "lh", "rh"):
+        d["pd_" + f] = np.zeros(3); d["pdd_" + f] = np.zeros(3)
+    d.update(rpy_body=np.zeros(3), p_body=np.array([0, 0, 0.3]), rpyd_body=np.zeros(3), pd_body=np.zeros(3),
+             rpydd_body=np.zeros(3), pdd_body=np.zeros(3), contact_states=[True, False, True, True],
+             f_cj=np.zeros((3, 4)), u2_max=0.0)
+    t, mask = pack_trunk_input(d)
+    assert mask == 0b1101
+    assert np.allclose(t[0:3], [0, 0, 0.3]) and np.allclose(t[18:21], [0.175, 0.11, 0]) and np.allclose(t[45:48], [-0.2, -0.11, 0])
+    from quadruped_drake_amd import workloads
+    assert np.allclose(workloads.standing_targets("mini_cheetah", 1)[:, 0], t)
+
+
+def test_model_tables_are_committed_and_sane():
+    from quadruped_drake_amd.controller import load_model
+    for name, mass in (("mini_cheetah", 8.252), ("anymal_b", 30.4214)):
+        t = load_model(name)
+        assert len(t["flat"]) == 215 and abs(t["total_mass"] - mass) < 1e-3
+        assert sorted(t["act_perm"]) == list(range(12))
+
+
+def test_workload_generators_are_seeded_and_shaped():
+    from quadruped_drake_amd import workloads
+    a = workloads.make_batch(3, n=64); b = workloads.make_batch(3, n=64)
+    assert all(np.array_equal(a[k], b[k]) for k in ("q", "v", "targets", "mask"))
+    assert a["q"].shape == (19, 64) and a["v"].shape == (18, 64) and a["targets"].shape == (54, 64)
+    assert set(np.unique(a["mask"])) <= {0b1001, 0b0110}
+    assert np.allclose(np.linalg.norm(a["q"][:4], axis=0), 1.0)
+    c = workloads.make_batch(5, n=32)
+    assert c["mu"].min() >= 0.4 and c["mu"].max() <= 1.0 and c["mass_scale"].min() >= 0.8
+    assert (workloads.make_batch(2, n=8)["mask"] == 0b1111).all()

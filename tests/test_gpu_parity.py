@@ -1,0 +1,217 @@
+"""-m gpu: the HIP path, called through the C ABI (include/wbc.h), against the oracle and the
+committed golden vectors.  Tolerance: north_star asks for torques within 1e-4 relative of the CPU
+reference; the measured error is ~1e-7 (ill-conditioning of the eps2 tie-break)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; the product has no CPU fallback"
+    return torch
+
+
+def rel_err(tau, tau_o):
+    return np.abs(tau - tau_o).max(0) / np.maximum(np.abs(tau_o).max(0), 1e-3)
+
+
+def gpu_step(kind, model, q, v, tg, mask, mu=None, ms=None, params=None, max_batch=None, **kw):
+    torch = _torch()
+    from quadruped_drake_amd import IDController, MPTCController
+    cls = IDController if kind == "id" else MPTCController
+    n = q.shape[1]
+    ctrl = cls(model=model, max_batch=max_batch or n, device=0, params=params, **kw)
+    up = lambda x: None if x is None else torch.tensor(np.ascontiguousarray(x), device="cuda:0")
+    tau, met, st = ctrl.step(up(q), up(v), up(tg), up(mask), up(mu), up(ms))
+    ctrl.sync()
+    out = tau.cpu().numpy(), met.cpu().numpy(), st.cpu().numpy()
+    stats = ctrl.stats()
+    ctrl.close()
+    return out + (stats,)
+
+
+def load_gold(path):
+    z = np.load(path)
+    d = {k: z[k] for k in z.files}
+    d["model"] = str(d["model"]); d["kind"] = str(d["kind"])
+    d["mu"] = d["mu"] if d["mu"].size else None
+    d["mass_scale"] = d["mass_scale"] if d["mass_scale"].size else None
+    return d
+
+
+def test_native_library_is_the_one_loaded():
+    _torch()
+    from quadruped_drake_amd import _lib
+    _lib.lib()
+    with open("/proc/self/maps") as f:
+        assert "libwbc_hip.so" in f.read()
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_gpu_matches_golden_vectors(path):
+    g = load_gold(path)
+    tau, met, st, _ = gpu_step(g["kind"], g["model"], g["q"], g["v"], g["targets"], g["mask"], g["mu"], g["mass_scale"])
+    assert np.array_equal(st, g["status"])
+    assert rel_err(tau, g["tau"]).max() < TOL
+    assert np.allclose(met, g["metrics"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("cfg,kind,n", [(2, "id", 1024), (3, "mptc", 2048), (4, "mptc", 1024), (5, "mptc", 1024), (3, "id", 512)])
+def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n):
+    from oracle import oracle_py as orc
+    from quadruped_drake_amd import workloads
+    b = workloads.make_batch(cfg, n=n)
+    tau, met, st, stats = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
+    m = orc.model(b["model"]); p = orc.params(kind)
+    tau_o, met_o, st_o = orc.step_batch(kind, m, p, b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
+    assert (st == 0).all() and (st_o == 0).all()
+    r = rel_err(tau, tau_o)
+    assert r.max() < TOL, r.max()
+    assert np.median(r) < 1e-9
+    assert np.allclose(met, met_o, rtol=1e-5, atol=1e-6)
+    # device-side end-of-rollout statistics agree with the outputs
+    assert stats["ticks"] == n and stats["status_nonzero"] == 0
+    assert abs(stats["tau_abs_sum"] - np.abs(tau).sum()) < 1e-9 * np.abs(tau).sum()
+    assert stats["tau_abs_max"] == np.abs(tau).max()
+    assert stats["mask_count"] == [float((b["mask"] == k).sum()) for k in range(16)]
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 200])
+def test_ragged_batch_sizes(n):
+    from oracle import oracle_py as orc
+    from quadruped_drake_amd import workloads
+    b = workloads.make_batch(3, n=n)
+    tau, met, st, _ = gpu_step("mptc", b["model"], b["q"], b["v"], b["targets"], b["mask"], max_batch=256)
+    tau_o, _, _ = orc.step_batch("mptc", orc.model(b["model"]), orc.params("mptc"), b["q"], b["v"], b["targets"], b["mask"])
+    assert tau.shape == (12, n) and (st == 0).all()
+    assert rel_err(tau, tau_o).max() < TOL
+
+
+def test_empty_batch_and_misuse():
+    torch = _torch()
+    from quadruped_drake_amd import MPTCController, _lib
+    ctrl = MPTCController(max_batch=16, device=0)
+    e = lambda r: torch.empty((r, 0), dtype=torch.float64, device="cuda:0")
+    tau, met, st = ctrl.step(e(19), e(18), e(54), torch.empty((0,), dtype=torch.uint8, device="cuda:0"))
+    assert tau.shape == (12, 0)
+    z = lambda r, n: torch.zeros((r, n), dtype=torch.float64, device="cuda:0")
+    with pytest.raises(_lib.WbcError):           # n > max_batch
+        ctrl.step(z(19, 32), z(18, 32), z(54, 32), torch.zeros((32,), dtype=torch.uint8, device="cuda:0"))
+    with pytest.raises(ValueError):              # wrong dtype
+        ctrl.step(z(19, 4).float(), z(18, 4), z(54, 4), torch.zeros((4,), dtype=torch.uint8, device="cuda:0"))
+    ctrl.close()
+
+
+def test_torque_box_friction_and_host_pointer_mode():
+    from oracle import oracle_py as orc
+    from quadruped_drake_amd import IDController, workloads
+    _torch()
+    b = workloads.make_batch(2, n=96)
+    params = {"tau_max": 14.0, "mu": 0.5}
+    ctrl = IDController(model=b["model"], max_batch=128, device=0, params=params, host_ptrs=True)
+    tau, met, st = ctrl.step(b["q"], b["v"], b["targets"], b["mask"])
+    ctrl.close()
+    p = orc.params("id"); p.tau_max = 14.0; p.mu = 0.5
+    tau_o, met_o, st_o = orc.step_batch("id", orc.model(b["model"]), p, b["q"], b["v"], b["targets"], b["mask"])
+    assert np.array_equal(st == 0, st_o == 0)
+    ok = st == 0
+    assert ok.sum() > 48 and np.abs(tau[:, ok]).max() <= 14.0 + 1e-9
+    assert rel_err(tau[:, ok], tau_o[:, ok]).max() < TOL
+
+
+def test_joint_and_actuator_permutations():
+    from quadruped_drake_amd import workloads
+    b = workloads.make_batch(3, n=64)
+    rng = np.random.default_rng(0)
+    qperm = rng.permutation(12); aperm = rng.permutation(12)
+    q2 = b["q"].copy(); v2 = b["v"].copy()
+    q2[7 + qperm] = b["q"][7:]; v2[6 + qperm] = b["v"][6:]
+    tau, _, _, _ = gpu_step("mptc", b["model"], b["q"], b["v"], b["targets"], b["mask"], act_perm=list(range(12)))
+    tau2, _, _, _ = gpu_step("mptc", b["model"], q2, v2, b["targets"], b["mask"], q_perm=qperm, act_perm=aperm)
+    assert np.array_equal(tau2, tau[aperm])
+
+
+def test_single_robot_control_law_mirrors_reference_signature():
+    """q0 of simulate.py:171-176 with the SimpleStanding dict of planners/simple.py:39-85."""
+    from oracle import oracle_py as orc
+    from quadruped_drake_amd import IDController, MPTCController, workloads
+    _torch()
+    q, v = workloads.nominal_state("mini_cheetah", 1)
+    d = {}
+    for i, f in enumerate(("lf", "rf", "lh", "rh")):
+        d["p_" + f] = workloads.STAND_FEET["mini_cheetah"][i]; d["pd_" + f] = np.zeros(3); d["pdd_" + f] = np.zeros(3)
+    d.update(rpy_body=np.zeros(3), p_body=np.array([0, 0, 0.3]), rpyd_body=np.zeros(3), pd_body=np.zeros(3),
+             rpydd_body=np.zeros(3), pdd_body=np.zeros(3), contact_states=[True] * 4, f_cj=np.zeros((3, 4)), u2_max=0.0)
+    for cls, kind in ((IDController, "id"), (MPTCController, "mptc")):
+        c = cls(max_batch=1, device=0)
+        u = c.ControlLaw(q[:, 0], v[:, 0], d)
+        c.close()
+        tg = workloads.standing_targets("mini_cheetah", 1)[:, 0]
+        u_o, met_o, st_o = orc.control_law(kind, orc.model("mini_cheetah"), orc.params(kind), q[:, 0], v[:, 0], tg, [1, 1, 1, 1])
+        assert st_o == 0 and np.abs(u - u_o).max() < 1e-6 * (1 + np.abs(u_o).max())
+
+
+@pytest.mark.parametrize("cfg,n", [(3, 4096), (5, 32768)])
+def test_full_size_properties(cfg, n):
+    """BASELINE full sizes: size-independent properties instead of the (slow) oracle."""
+    torch = _torch()
+    from quadruped_drake_amd import MPTCController, workloads
+    b = workloads.make_batch(cfg, n=n)
+    ctrl = MPTCController(model=b["model"], max_batch=n, device=0)
+    up = lambda x: None if x is None else torch.tensor(x, device="cuda:0")
+    q, v, tg, mask, mu, ms = (up(b[k]) for k in ("q", "v", "targets", "mask", "mu", "mass_scale"))
+    tau, met, st = ctrl.step(q, v, tg, mask, mu, ms)
+    ctrl.sync()
+    tau1 = tau.cpu().numpy().copy(); st1 = st.cpu().numpy().copy(); met1 = met.cpu().numpy().copy()
+    assert (st1 == 0).all() and np.isfinite(tau1).all() and np.isfinite(met1).all()
+    # determinism: a second launch is bit-identical
+    tau2, _, _ = ctrl.step(q, v, tg, mask, mu, ms)
+    ctrl.sync()
+    assert np.array_equal(tau2.cpu().numpy(), tau1)
+    # invariance to batch position: permute the instances
+    perm = torch.randperm(n, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(1))
+    g = lambda x: None if x is None else (x[:, perm].contiguous() if x.dim() == 2 else x[perm].contiguous())
+    tau3, _, _ = ctrl.step(g(q), g(v), g(tg), g(mask), g(mu), g(ms))
+    ctrl.sync()
+    assert np.array_equal(tau3.cpu().numpy(), tau1[:, perm.cpu().numpy()])
+    # MPTC passivity metric: V >= 0 ; err >= 0
+    assert (met1[0] >= 0).all() and (met1[1] >= 0).all()
+    # spot-check 64 instances against the oracle
+    from oracle import oracle_py as orc
+    idx = np.linspace(0, n - 1, 64).astype(int)
+    sl = lambda a: None if a is None else (a[:, idx] if a.ndim == 2 else a[idx])
+    tau_o, _, _ = orc.step_batch("mptc", orc.model(b["model"]), orc.params("mptc"), sl(b["q"]), sl(b["v"]),
+                                 sl(b["targets"]), sl(b["mask"]), sl(b["mu"]), sl(b["mass_scale"]))
+    assert rel_err(tau1[:, idx], tau_o).max() < TOL
+    ctrl.close()
+
+
+def test_sub_batch_with_leading_dimension():
+    """ld > n: a shard of a larger SoA array is stepped in place (what a multi-GPU shard does)."""
+    torch = _torch()
+    import ctypes as C
+    from quadruped_drake_amd import MPTCController, _lib, workloads
+    b = workloads.make_batch(3, n=256)
+    ctrl = MPTCController(max_batch=256, device=0)
+    up = lambda x: torch.tensor(x, device="cuda:0")
+    q, v, tg, mask = up(b["q"]), up(b["v"]), up(b["targets"]), up(b["mask"])
+    tau_full, _, _ = ctrl.step(q, v, tg, mask)
+    ctrl.sync()
+    tau = torch.zeros((12, 256), dtype=torch.float64, device="cuda:0")
+    lo, n = 64, 100
+    P = lambda t, off: C.c_void_p(t.data_ptr() + off)
+    _lib.check(ctrl._L.wbc_step(ctrl._h, n, 256, P(q, lo * 8), P(v, lo * 8), P(tg, lo * 8), P(mask, lo), None, None,
+                                P(tau, lo * 8), None, None))
+    ctrl.sync()
+    t = tau.cpu().numpy()
+    assert np.array_equal(t[:, lo:lo + n], tau_full.cpu().numpy()[:, lo:lo + n])
+    assert (t[:, :lo] == 0).all() and (t[:, lo + n:] == 0).all()
+    ctrl.close()
