@@ -54,17 +54,15 @@ def cpu_baseline(batch, seconds):
     t = time.perf_counter()
     orc.step_batch(batch["kind"], m, p, *args(n0), nthreads=1)
     rate1 = n0 / (time.perf_counter() - t)
-    n = int(min(batch["n"], max(n0, rate1 * seconds)))
-    # all cores over the sample; repeat the sample if the batch is too small for the time target
+    n = batch["n"]
     reps = max(1, int(round(rate1 * seconds / n)))
     t = time.perf_counter()
-    for _ in range(reps):
-        orc.step_batch(batch["kind"], m, p, *args(n), nthreads=cores)
+    orc.bench_batch(batch["kind"], m, p, *args(n), nthreads=cores, reps=reps)   # one OpenMP region
     dt = time.perf_counter() - t
     return {"value": n * reps / dt, "unit": "ticks/s", "cores": cores, "kind": "port",
             "single_core_ticks_per_s": rate1,
-            "sample": "first %d instances of the same batch x %d passes, C oracle (dense restatement of the "
-                      "Drake+OSQP tick), OpenMP over instances" % (n, reps)}
+            "sample": "the same %d-instance batch x %d passes (one OpenMP region, dynamic schedule), C oracle = dense "
+                      "restatement of the Drake+OSQP tick" % (n, reps)}
 
 
 def main():

@@ -190,3 +190,19 @@ def step_batch(kind, m, p, q, v, targets, mask, mu=None, mass_scale=None, nthrea
                          mask.ctypes.data_as(C.POINTER(C.c_ubyte)), mu_p, ms_p, _p(tau), _p(met),
                          st.ctypes.data_as(c_int_p), int(nthreads))
     return tau, met, st
+
+
+def bench_batch(kind, m, p, q, v, targets, mask, mu=None, mass_scale=None, nthreads=0, reps=1):
+    """`reps` passes over the batch inside one OpenMP region; returns tau of the last pass."""
+    q, v, targets = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, v, targets))
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    n = q.shape[1]
+    tau = np.zeros((12, n)); st = np.zeros(n, dtype=np.int32)
+    mu_a = np.ascontiguousarray(mu, dtype=np.float64) if mu is not None else None
+    ms_a = np.ascontiguousarray(mass_scale, dtype=np.float64) if mass_scale is not None else None
+    kind_i = 0 if kind in (0, "id", "ID") else 1
+    lib().orc_bench_batch(C.byref(m), C.byref(p), kind_i, n, n, _p(q), _p(v), _p(targets),
+                          mask.ctypes.data_as(C.POINTER(C.c_ubyte)), _p(mu_a) if mu_a is not None else None,
+                          _p(ms_a) if ms_a is not None else None, _p(tau), st.ctypes.data_as(c_int_p),
+                          int(nthreads), int(reps))
+    return tau, st

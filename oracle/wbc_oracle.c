@@ -936,7 +936,7 @@ int orc_step_batch(const orc_model* m, const orc_params* p, int kind, int n, int
 #else
   (void)nthreads;
 #endif
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel for schedule(dynamic, 8)
   for (int i = 0; i < n; i++) {
     double qi[19], vi[18], tg[54], ti[12], mi[4];
     int ct[4];
@@ -956,6 +956,43 @@ int orc_step_batch(const orc_model* m, const orc_params* p, int kind, int n, int
     for (int k = 0; k < 12; k++) tau[(size_t)k * stride + i] = ti[k];
     if (metrics) for (int k = 0; k < 4; k++) metrics[(size_t)k * stride + i] = mi[k];
     if (status) status[i] = st;
+  }
+  return 0;
+}
+
+/* Timing driver for bench.py's cpu_baseline leg: `reps` passes over the n instances inside ONE
+ * OpenMP parallel region (the outputs of the last pass are kept). */
+int orc_bench_batch(const orc_model* m, const orc_params* p, int kind, int n, int stride, const double* q,
+                    const double* v, const double* targets, const unsigned char* mask, const double* mu,
+                    const double* mass_scale, double* tau, int* status, int nthreads, int reps) {
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+  (void)nthreads;
+#endif
+  long total = (long)n * reps;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (long j = 0; j < total; j++) {
+    int i = (int)(j % n);
+    double qi[19], vi[18], tg[54], ti[12], mi[4];
+    int ct[4];
+    for (int k = 0; k < 19; k++) qi[k] = q[(size_t)k * stride + i];
+    for (int k = 0; k < 18; k++) vi[k] = v[(size_t)k * stride + i];
+    for (int k = 0; k < 54; k++) tg[k] = targets[(size_t)k * stride + i];
+    for (int k = 0; k < 4; k++) ct[k] = (mask[i] >> k) & 1;
+    orc_model ml = *m;
+    orc_params pl = *p;
+    if (mu) pl.mu = mu[i];
+    if (mass_scale) {
+      ml.base_mass *= mass_scale[i];
+      for (int k = 0; k < 6; k++) ml.base_I[k] *= mass_scale[i];
+    }
+    int st = (kind == 0) ? orc_id_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
+                         : orc_mptc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL);
+    if (j >= total - n) {
+      for (int k = 0; k < 12; k++) tau[(size_t)k * stride + i] = ti[k];
+      if (status) status[i] = st;
+    }
   }
   return 0;
 }

@@ -119,6 +119,11 @@ int orc_step_batch(const orc_model* m, const orc_params* p, int kind, int n, int
                    const double* v, const double* targets, const unsigned char* mask, const double* mu,
                    const double* mass_scale, double* tau, double* metrics, int* status, int nthreads);
 
+/* Timing driver (bench.py cpu_baseline): `reps` passes inside one OpenMP parallel region. */
+int orc_bench_batch(const orc_model* m, const orc_params* p, int kind, int n, int stride, const double* q,
+                    const double* v, const double* targets, const unsigned char* mask, const double* mu,
+                    const double* mass_scale, double* tau, int* status, int nthreads, int reps);
+
 #ifdef __cplusplus
 }
 #endif
