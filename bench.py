@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--per-gpu", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--config", type=int, default=0, help="override workload config (2,3,4,5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", default="auto", choices=["auto", "lane", "quad"], help="kernel variant (A/B runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work (core-seconds) for the baseline sample")
     return ap.parse_args()
 
@@ -93,6 +94,7 @@ def main():
     n = shard["n"]
     cls = IDController if shard["kind"] == "id" else MPTCController
     ctrl = cls(model=shard["model"], max_batch=n, device=local)
+    ctrl.set_variant(a.variant)
     up = lambda x: None if x is None else torch.tensor(x, device=dev)
     q, v, tg, mask, mu, ms = (up(shard[k]) for k in ("q", "v", "targets", "mask", "mu", "mass_scale"))
     out = (torch.empty((12, n), dtype=torch.float64, device=dev), torch.empty((4, n), dtype=torch.float64, device=dev),
@@ -139,7 +141,7 @@ def main():
                 "domain_randomised": mu is not None, "parallelism": "batch-shard x%d" % world},
             "roofline": {"bound": "valu-f64", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": None,
-                         "kernel": "wbc_tick_kernel<%s>" % shard["kind"].upper(),
+                         "kernel": "%s<%s>" % ("wbc_tick_kernel" if a.variant == "lane" else "wbc_quad_kernel", shard["kind"].upper()),
                          "kernel_ms": ms_per_launch, "flops_per_tick": flops,
                          "hbm": {"achieved_GBs": bpt * n / sec / 1e9, "peak_GBs": PEAK_HBM_GBS,
                                  "frac": bpt * n / sec / 1e9 / PEAK_HBM_GBS, "bytes_per_tick": bpt},

@@ -122,6 +122,10 @@ int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, cons
 int wbc_stats_get(wbc_handle h, wbc_stats* out);
 int wbc_stats_reset(wbc_handle h);
 
+/* Kernel variant: 0 = auto (default), 1 = lane-per-robot, 2 = quad-per-robot (4 lanes = 4 legs).
+ * Both compute the same tick; auto picks quad unless the optional torque box is enabled. */
+int wbc_set_variant(wbc_handle h, int variant);
+
 /* Kernel resource report for the handle's kind: registers, scratch bytes/lane, LDS bytes. */
 int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads);
 

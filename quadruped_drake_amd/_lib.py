@@ -15,7 +15,8 @@ DEVICE_PTRS, HOST_PTRS = 0, 1
 
 # every symbol include/wbc.h declares
 SYMBOLS = ["wbc_last_error", "wbc_version", "wbc_params_default", "wbc_create", "wbc_destroy", "wbc_set_stream",
-           "wbc_step", "wbc_sync", "wbc_time_steps", "wbc_stats_get", "wbc_stats_reset", "wbc_kernel_info"]
+           "wbc_step", "wbc_sync", "wbc_time_steps", "wbc_stats_get", "wbc_stats_reset", "wbc_set_variant",
+           "wbc_kernel_info"]
 
 
 class WbcModel(C.Structure):
@@ -61,6 +62,7 @@ def lib():
         l.wbc_time_steps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.POINTER(C.c_float)]
         l.wbc_stats_get.argtypes = [C.c_void_p, C.POINTER(WbcStats)]
         l.wbc_stats_reset.argtypes = [C.c_void_p]
+        l.wbc_set_variant.argtypes = [C.c_void_p, C.c_int]
         l.wbc_kernel_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
         for s in SYMBOLS:
             getattr(l, s)

@@ -170,6 +170,11 @@ class BatchedController:
             _lib.check(self._L.wbc_stats_reset(self._h))
         return d
 
+    def set_variant(self, variant):
+        """0 = auto, 1 = lane-per-robot kernel, 2 = quad-per-robot kernel."""
+        v = {"auto": 0, "lane": 1, "quad": 2}.get(variant, variant)
+        _lib.check(self._L.wbc_set_variant(self._h, int(v)))
+
     def kernel_info(self):
         a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _lib.check(self._L.wbc_kernel_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))

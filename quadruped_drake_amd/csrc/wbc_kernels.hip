@@ -15,6 +15,7 @@
 #include "../../include/wbc.h"
 #include "wbc_model.hpp"
 #include "wbc_tick.hpp"
+#include "wbc_quad.hpp"
 
 namespace {
 
@@ -104,10 +105,117 @@ wbc_tick_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
   }
 }
 
+// ---------------------------------------------------------------- v2: quad-per-robot kernel
+// Quad communication on DPP quad_perm (no LDS, no ds_bpermute): 2 v_mov_dpp per double.
+struct QuadDev {
+  int l;
+  __device__ QuadDev() : l(threadIdx.x & 3) {}
+  __device__ __forceinline__ int lane() const { return l; }
+  template <int CTRL> static __device__ __forceinline__ int dppi(int x) {
+    return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false);
+  }
+  template <int CTRL> static __device__ __forceinline__ double dpp(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = dppi<CTRL>(lo);
+    hi = dppi<CTRL>(hi);
+    return __hiloint2double(hi, lo);
+  }
+  __device__ __forceinline__ double bcast_s(double x, int src) const {
+    switch (src) {
+      case 0: return dpp<0x00>(x);
+      case 1: return dpp<0x55>(x);
+      case 2: return dpp<0xAA>(x);
+      default: return dpp<0xFF>(x);
+    }
+  }
+  __device__ __forceinline__ double sum(double x) const {
+    x += dpp<0xB1>(x);  // quad_perm [1,0,3,2]
+    x += dpp<0x4E>(x);  // quad_perm [2,3,0,1]
+    return x;
+  }
+  __device__ __forceinline__ double max(double x) const {
+    x = fmax(x, dpp<0xB1>(x));
+    x = fmax(x, dpp<0x4E>(x));
+    return x;
+  }
+  __device__ __forceinline__ bool any(bool b) const {
+    int x = b ? 1 : 0;
+    x |= dppi<0xB1>(x);
+    x |= dppi<0x4E>(x);
+    return x != 0;
+  }
+  static __device__ __forceinline__ void amin(double& v, int& i, double ov, int oi) {
+    if (ov < v || (ov == v && oi >= 0 && (i < 0 || oi < i))) { v = ov; i = oi; }
+  }
+  __device__ __forceinline__ void argmin(double& v, int& i) const {
+    amin(v, i, dpp<0xB1>(v), dppi<0xB1>(i));
+    amin(v, i, dpp<0x4E>(v), dppi<0x4E>(i));
+  }
+};
+
+constexpr int QROBOTS = BLOCK / 4;  // robots per 64-lane block
+
+template <int KIND>
+__global__ void __launch_bounds__(BLOCK)
+wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld,
+                const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
+                const uint8_t* __restrict__ mask, const double* __restrict__ mu,
+                const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
+                int32_t* __restrict__ status, StatsDev* __restrict__ stats) {
+  __shared__ wbc::QuadShared shq[QROBOTS];
+  const int slot = threadIdx.x >> 2;
+  const int i = blockIdx.x * QROBOTS + slot;
+  const bool live = i < n;
+  const int ii = live ? i : (n - 1);
+  const wbc::ModelC& m = *mp;
+  const wbc::ParamsC& P = *pp;
+  QuadDev qo;
+  auto in = [&](int r) -> double {
+    if (r < 19) return q[(size_t)r * ld + ii];
+    if (r < 37) return v[(size_t)(r - 19) * ld + ii];
+    return tg[(size_t)(r - 37) * ld + ii];
+  };
+  double tsum = 0.0, tmax = 0.0, errv = 0.0;
+  auto ot = [&](int k, double x) {
+    if (live) tau[(size_t)k * ld + ii] = x;
+    tsum += fabs(x);
+    tmax = fmax(tmax, fabs(x));
+  };
+  const bool lead = qo.l == 0;
+  auto om = [&](int k, double x) {
+    if (live && lead && met) met[(size_t)k * ld + ii] = x;
+    if (k == 1) errv = x;
+  };
+  const unsigned mk = mask[ii] & 0xF;
+  const double mui = mu ? mu[ii] : P.mu;
+  const double msi = ms ? ms[ii] : 1.0;
+  int iters = 0;
+  const int st = wbc::quad_tick<QuadDev, KIND>(m, P, qo, in, mk, mui, msi, shq[slot], ot, om, &iters);
+  if (live && lead && status) status[ii] = st;
+  if (stats) {
+    const double lv = (live && lead) ? 1.0 : 0.0, la = live ? 1.0 : 0.0;
+    double a = wave_sum(lv), b = wave_sum((live && lead && st != 0) ? 1.0 : 0.0), c = wave_sum(lv * iters);
+    double d = wave_sum(la * tsum), e = wave_max(la * tmax), f = wave_sum(lv * errv);
+    unsigned long long bal[16];
+    for (int k = 0; k < 16; k++) bal[k] = __ballot(live && lead && mk == (unsigned)k);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&stats->ticks, a);
+      if (b != 0.0) atomicAdd(&stats->status_nonzero, b);
+      atomicAdd(&stats->iters_sum, c);
+      atomicAdd(&stats->tau_abs_sum, d);
+      atomicMax(&stats->tau_abs_max_bits, (unsigned long long)__double_as_longlong(e));
+      atomicAdd(&stats->err_sum, f);
+      for (int k = 0; k < 16; k++)
+        if (bal[k]) atomicAdd(&stats->mask_count[k], (double)__popcll(bal[k]));
+    }
+  }
+}
+
 }  // namespace
 
 struct wbc_handle_s {
-  int kind, max_batch, device;
+  int kind, max_batch, device, variant;
+  bool torque_box;
   uint32_t flags;
   hipStream_t stream;
   bool own_stream;
@@ -157,6 +265,8 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
   wbc_handle h = new wbc_handle_s();
   memset(h, 0, sizeof *h);
   h->kind = kind; h->max_batch = max_batch; h->device = device; h->flags = flags;
+  h->variant = 0;
+  h->torque_box = P.tau_max < 1e300;
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->own_stream = true;
   HIP_TRY(hipMalloc(&h->d_model, sizeof m));
@@ -207,13 +317,27 @@ int wbc_set_stream(wbc_handle h, void* hip_stream) {
 static int launch(wbc_handle h, int n, int ld, const double* q, const double* v, const double* tg,
                   const uint8_t* mask, const double* mu, const double* ms, double* tau, double* met,
                   int32_t* status) {
-  dim3 grid((n + BLOCK - 1) / BLOCK), block(BLOCK);
-  if (h->kind == WBC_KIND_ID)
-    hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_ID>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q,
-                       v, tg, mask, mu, ms, tau, met, status, h->d_stats);
-  else
-    hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_MPTC>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld,
-                       q, v, tg, mask, mu, ms, tau, met, status, h->d_stats);
+  // variant 0 = auto: the quad kernel (4 lanes per robot) unless the optional torque box is on,
+  // which only the lane-per-robot kernel implements.
+  const bool quad = (h->variant == 2) || (h->variant == 0 && !h->torque_box);
+  dim3 block(BLOCK);
+  if (quad) {
+    dim3 grid((n + QROBOTS - 1) / QROBOTS);
+    if (h->kind == WBC_KIND_ID)
+      hipLaunchKernelGGL(wbc_quad_kernel<wbc::KIND_ID>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q,
+                         v, tg, mask, mu, ms, tau, met, status, h->d_stats);
+    else
+      hipLaunchKernelGGL(wbc_quad_kernel<wbc::KIND_MPTC>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld,
+                         q, v, tg, mask, mu, ms, tau, met, status, h->d_stats);
+  } else {
+    dim3 grid((n + BLOCK - 1) / BLOCK);
+    if (h->kind == WBC_KIND_ID)
+      hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_ID>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q,
+                         v, tg, mask, mu, ms, tau, met, status, h->d_stats);
+    else
+      hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_MPTC>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld,
+                         q, v, tg, mask, mu, ms, tau, met, status, h->d_stats);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -303,10 +427,22 @@ int wbc_stats_reset(wbc_handle h) {
   return 0;
 }
 
+int wbc_set_variant(wbc_handle h, int variant) {
+  if (!h) return misuse("wbc_set_variant: null handle");
+  if (variant < 0 || variant > 2) return misuse("wbc_set_variant: 0 = auto, 1 = lane-per-robot, 2 = quad-per-robot");
+  if (variant == 2 && h->torque_box) return misuse("wbc_set_variant: the quad kernel has no torque box (tau_max must be +inf)");
+  h->variant = variant;
+  return 0;
+}
+
 int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads) {
   if (!h) return misuse("wbc_kernel_info: null handle");
   hipFuncAttributes a;
-  if (h->kind == WBC_KIND_ID) HIP_TRY(hipFuncGetAttributes(&a, (const void*)wbc_tick_kernel<wbc::KIND_ID>));
+  const bool quad = (h->variant == 2) || (h->variant == 0 && !h->torque_box);
+  if (quad) {
+    if (h->kind == WBC_KIND_ID) HIP_TRY(hipFuncGetAttributes(&a, (const void*)wbc_quad_kernel<wbc::KIND_ID>));
+    else HIP_TRY(hipFuncGetAttributes(&a, (const void*)wbc_quad_kernel<wbc::KIND_MPTC>));
+  } else if (h->kind == WBC_KIND_ID) HIP_TRY(hipFuncGetAttributes(&a, (const void*)wbc_tick_kernel<wbc::KIND_ID>));
   else HIP_TRY(hipFuncGetAttributes(&a, (const void*)wbc_tick_kernel<wbc::KIND_MPTC>));
   if (num_vgpr) *num_vgpr = a.numRegs;
   if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;

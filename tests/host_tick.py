@@ -17,9 +17,10 @@ def lib():
         so = os.path.join(_ROOT, "tools", "libhost_tick.so")
         srcs = [os.path.join(_ROOT, "tools", "host_tick.cpp"),
                 os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_tick.hpp"),
-                os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_model.hpp")]
+                os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_model.hpp"),
+                os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_quad.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+            subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
                                    "-o", so, srcs[0]])
         _LIB = C.CDLL(so)
     return _LIB
@@ -29,7 +30,8 @@ def _p(a):
     return a.ctypes.data_as(_dp) if a is not None else None
 
 
-def run(kind, flat, q, v, targets, mask, mu=None, mass_scale=None, params12=None, q_perm=None, act_perm=None):
+def run(kind, flat, q, v, targets, mask, mu=None, mass_scale=None, params12=None, q_perm=None, act_perm=None,
+        quad=False):
     q, v, targets = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, v, targets))
     mask = np.ascontiguousarray(mask, dtype=np.uint8)
     flat = np.ascontiguousarray(flat, dtype=np.float64)
@@ -41,7 +43,8 @@ def run(kind, flat, q, v, targets, mask, mu=None, mass_scale=None, params12=None
     qp = None if q_perm is None else np.ascontiguousarray(q_perm, dtype=np.int32)
     ap = None if act_perm is None else np.ascontiguousarray(act_perm, dtype=np.int32)
     k = 0 if kind in (0, "id", "ID") else 1
-    rc = lib().host_tick_batch(k, _p(flat), _p(pp), qp.ctypes.data_as(_ip) if qp is not None else None,
+    fn = lib().host_quad_batch if quad else lib().host_tick_batch
+    rc = fn(k, _p(flat), _p(pp), qp.ctypes.data_as(_ip) if qp is not None else None,
                                ap.ctypes.data_as(_ip) if ap is not None else None, n, n, _p(q), _p(v),
                                _p(targets), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), _p(mu), _p(ms),
                                _p(tau), _p(met), st.ctypes.data_as(_ip), it.ctypes.data_as(_ip))

@@ -23,12 +23,13 @@ def rel_err(tau, tau_o):
     return np.abs(tau - tau_o).max(0) / np.maximum(np.abs(tau_o).max(0), 1e-3)
 
 
-def gpu_step(kind, model, q, v, tg, mask, mu=None, ms=None, params=None, max_batch=None, **kw):
+def gpu_step(kind, model, q, v, tg, mask, mu=None, ms=None, params=None, max_batch=None, variant="auto", **kw):
     torch = _torch()
     from quadruped_drake_amd import IDController, MPTCController
     cls = IDController if kind == "id" else MPTCController
     n = q.shape[1]
     ctrl = cls(model=model, max_batch=max_batch or n, device=0, params=params, **kw)
+    ctrl.set_variant(variant)
     up = lambda x: None if x is None else torch.tensor(np.ascontiguousarray(x), device="cuda:0")
     tau, met, st = ctrl.step(up(q), up(v), up(tg), up(mask), up(mu), up(ms))
     ctrl.sync()
@@ -55,21 +56,25 @@ def test_native_library_is_the_one_loaded():
         assert "libwbc_hip.so" in f.read()
 
 
+@pytest.mark.parametrize("variant", ["quad", "lane"])
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
-def test_gpu_matches_golden_vectors(path):
+def test_gpu_matches_golden_vectors(path, variant):
     g = load_gold(path)
-    tau, met, st, _ = gpu_step(g["kind"], g["model"], g["q"], g["v"], g["targets"], g["mask"], g["mu"], g["mass_scale"])
+    tau, met, st, _ = gpu_step(g["kind"], g["model"], g["q"], g["v"], g["targets"], g["mask"], g["mu"], g["mass_scale"],
+                               variant=variant)
     assert np.array_equal(st, g["status"])
     assert rel_err(tau, g["tau"]).max() < TOL
     assert np.allclose(met, g["metrics"], rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("variant", ["quad", "lane"])
 @pytest.mark.parametrize("cfg,kind,n", [(2, "id", 1024), (3, "mptc", 2048), (4, "mptc", 1024), (5, "mptc", 1024), (3, "id", 512)])
-def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n):
+def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n, variant):
     from oracle import oracle_py as orc
     from quadruped_drake_amd import workloads
     b = workloads.make_batch(cfg, n=n)
-    tau, met, st, stats = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
+    tau, met, st, stats = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"],
+                                   variant=variant)
     m = orc.model(b["model"]); p = orc.params(kind)
     tau_o, met_o, st_o = orc.step_batch(kind, m, p, b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
     assert (st == 0).all() and (st_o == 0).all()
@@ -84,7 +89,7 @@ def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n):
     assert stats["mask_count"] == [float((b["mask"] == k).sum()) for k in range(16)]
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 200])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 200])
 def test_ragged_batch_sizes(n):
     from oracle import oracle_py as orc
     from quadruped_drake_amd import workloads

@@ -69,3 +69,28 @@ def test_permutations():
     tau, _, _, _ = ht.run("mptc", t["flat"], b["q"], b["v"], b["targets"], b["mask"])
     tau2, _, _, _ = ht.run("mptc", t["flat"], q2, v2, b["targets"], b["mask"], q_perm=qperm, act_perm=aperm)
     assert np.array_equal(tau2, tau[aperm])
+
+
+@pytest.mark.parametrize("cfg,kind,n", [(2, "id", 24), (3, "mptc", 12), (4, "mptc", 8), (5, "mptc", 8)])
+def test_quad_kernel_math_emulated_on_host(cfg, kind, n):
+    """wbc_quad.hpp (4 lanes = 4 legs per robot) with the quad emulated by 4 host threads."""
+    b = workloads.make_batch(cfg, n=n)
+    t = orc.load_model_json(b["model"])
+    m = orc.model(b["model"]); p = orc.params(kind)
+    tau_o, met_o, st_o = orc.step_batch(kind, m, p, b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
+    tau, met, st, it = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"], quad=True)
+    assert (st == 0).all()
+    assert rel_err(tau, tau_o).max() < 1e-5
+    assert np.allclose(met, met_o, rtol=1e-7, atol=1e-8)
+
+
+def test_quad_all_contact_masks_on_host():
+    b = workloads.make_batch(3, n=16)
+    t = orc.load_model_json("mini_cheetah"); m = orc.model("mini_cheetah")
+    mk = np.arange(16, dtype=np.uint8)
+    for kind in ("id", "mptc"):
+        tau_o, met_o, st_o = orc.step_batch(kind, m, orc.params(kind), b["q"], b["v"], b["targets"], mk)
+        tau, met, st, it = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], mk, quad=True)
+        assert (st == 0).all()
+        assert rel_err(tau, tau_o).max() < 1e-5
+        assert np.allclose(met, met_o, rtol=1e-7, atol=1e-8)
