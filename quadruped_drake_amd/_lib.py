@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwbc_hip.so")
+LIB_PATH = os.environ.get("WBC_HIP_LIB", os.path.join(_HERE, "libwbc_hip.so"))  # override = A/B kernel builds
 
 c_double_p = C.POINTER(C.c_double)
 c_u8_p = C.POINTER(C.c_uint8)

@@ -13,6 +13,9 @@
 #include <string.h>
 
 #include "../../include/wbc.h"
+#ifdef WBC_STAMPS
+__device__ unsigned long long g_wbc_stamps[16 * 4096];
+#endif
 #include "wbc_model.hpp"
 #include "wbc_tick.hpp"
 #include "wbc_quad.hpp"
@@ -112,7 +115,7 @@ struct QuadDev {
   __device__ QuadDev() : l(threadIdx.x & 3) {}
   __device__ __forceinline__ int lane() const { return l; }
   template <int CTRL> static __device__ __forceinline__ int dppi(int x) {
-    return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false);
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);  // every quad lane is a valid source
   }
   template <int CTRL> static __device__ __forceinline__ double dpp(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
@@ -127,6 +130,10 @@ struct QuadDev {
       case 2: return dpp<0xAA>(x);
       default: return dpp<0xFF>(x);
     }
+  }
+  __device__ __forceinline__ double bcast_d(double x, int src) const {  // quad-uniform runtime source
+    const double a = dpp<0x00>(x), b = dpp<0x55>(x), c = dpp<0xAA>(x), d = dpp<0xFF>(x);
+    return (src & 2) ? ((src & 1) ? d : c) : ((src & 1) ? b : a);
   }
   __device__ __forceinline__ double sum(double x) const {
     x += dpp<0xB1>(x);  // quad_perm [1,0,3,2]
@@ -155,6 +162,58 @@ struct QuadDev {
 
 constexpr int QROBOTS = BLOCK / 4;  // robots per 64-lane block
 
+// Per-leg kinematics cache in LDS, element-major / lane-minor (element e of lane t at
+// arena[e*64 + t]): 64 consecutive doubles per element => ds_read/write_b64 are conflict-free.
+// The same arena is reused for the active-set factor (QuadShared) once the leg phase is over.
+struct LegKinLds {
+  double* a;  // arena + lane
+  // writes go through references; reads through a const LegKinLds are volatile so that the
+  // compiler re-reads LDS instead of forwarding the stored values through (scarce) registers
+  __device__ __forceinline__ double& at(int e) { return a[e * BLOCK]; }
+#ifndef WBC_KIN_VOLATILE
+#define WBC_KIN_VOLATILE 0
+#endif
+#if WBC_KIN_VOLATILE
+  __device__ __forceinline__ double ld(int e) const { return *(volatile const double*)(a + e * BLOCK); }
+#else
+  __device__ __forceinline__ double ld(int e) const { return a[e * BLOCK]; }
+#endif
+  __device__ __forceinline__ double& r(int k, int i) { return at(wbc::KIN_R + 3 * k + i); }
+  __device__ __forceinline__ double& ax(int k, int i) { return at(wbc::KIN_AX + 3 * k + i); }
+  __device__ __forceinline__ double& mcw(int k, int i) { return at(wbc::KIN_MCW + 3 * k + i); }
+  __device__ __forceinline__ double& Iw(int k, int i) { return at(wbc::KIN_IW + 6 * k + i); }
+  __device__ __forceinline__ double& rf(int i) { return at(wbc::KIN_RF + i); }
+  __device__ __forceinline__ double r(int k, int i) const { return ld(wbc::KIN_R + 3 * k + i); }
+  __device__ __forceinline__ double ax(int k, int i) const { return ld(wbc::KIN_AX + 3 * k + i); }
+  __device__ __forceinline__ double mcw(int k, int i) const { return ld(wbc::KIN_MCW + 3 * k + i); }
+  __device__ __forceinline__ double Iw(int k, int i) const { return ld(wbc::KIN_IW + 6 * k + i); }
+  __device__ __forceinline__ double rf(int i) const { return ld(wbc::KIN_RF + i); }
+};
+// Cold per-lane stage in LDS (same element-major layout).  Reads are volatile: a plain load would be
+// store-to-load forwarded, i.e. the value would stay in a register (or be spilled to scratch).
+struct StageLds {
+  double* a;  // stage base + lane
+  __device__ __forceinline__ void put(int i, double v) { a[i * BLOCK] = v; }
+#ifndef WBC_STAGE_VOLATILE
+#define WBC_STAGE_VOLATILE 1
+#endif
+#if WBC_STAGE_VOLATILE
+  __device__ __forceinline__ double get(int i) const { return *(volatile const double*)(a + i * BLOCK); }
+#else
+  __device__ __forceinline__ double get(int i) const { return a[i * BLOCK]; }
+#endif
+};
+// LDS map of one 64-lane block: [kinematics cache | stage | active-set factors]
+constexpr int KIN_DOUBLES = wbc::KIN_N * BLOCK;
+constexpr int STAGE_DOUBLES = wbc::ST_N * BLOCK;
+constexpr int SHQ_DOUBLES = (sizeof(wbc::QuadShared) * QROBOTS + 7) / 8;
+// Measured on MI355X (profiles/r01/variants.md): parking the stage in LDS does not beat the
+// compiler's own register/AGPR allocation at one wave per SIMD, so the product build keeps it in
+// registers and lets the active-set block alias the (dead by then) kinematics arena: 24.5 KB/block.
+#ifndef WBC_STAGE_IN_LDS
+#define WBC_STAGE_IN_LDS 0
+#endif
+
 template <int KIND>
 __global__ void __launch_bounds__(BLOCK)
 wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld,
@@ -162,7 +221,17 @@ wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
                 const uint8_t* __restrict__ mask, const double* __restrict__ mu,
                 const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
                 int32_t* __restrict__ status, StatsDev* __restrict__ stats) {
-  __shared__ wbc::QuadShared shq[QROBOTS];
+#if WBC_STAGE_IN_LDS
+  __shared__ double arena[KIN_DOUBLES + STAGE_DOUBLES + SHQ_DOUBLES];
+  StageLds stage{arena + KIN_DOUBLES + threadIdx.x};
+  wbc::QuadShared* shq = reinterpret_cast<wbc::QuadShared*>(arena + KIN_DOUBLES + STAGE_DOUBLES);
+#else
+  static_assert(SHQ_DOUBLES <= KIN_DOUBLES, "active-set block must fit the kinematics arena it aliases");
+  __shared__ double arena[KIN_DOUBLES];
+  wbc::StageReg<double> stage;
+  wbc::QuadShared* shq = reinterpret_cast<wbc::QuadShared*>(arena);
+#endif
+  LegKinLds kin{arena + threadIdx.x};
   const int slot = threadIdx.x >> 2;
   const int i = blockIdx.x * QROBOTS + slot;
   const bool live = i < n;
@@ -190,7 +259,8 @@ wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
   const double mui = mu ? mu[ii] : P.mu;
   const double msi = ms ? ms[ii] : 1.0;
   int iters = 0;
-  const int st = wbc::quad_tick<QuadDev, KIND>(m, P, qo, in, mk, mui, msi, shq[slot], ot, om, &iters);
+  const int st = wbc::quad_tick<QuadDev, KIND>(m, P, qo, in, mk, mui, msi, kin, stage, shq[slot], ot, om, &iters);
+  WBC_STAMP(14);
   if (live && lead && status) status[ii] = st;
   if (stats) {
     const double lv = (live && lead) ? 1.0 : 0.0, la = live ? 1.0 : 0.0;
@@ -253,8 +323,11 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
     int a = model->q_perm[i], b = model->act_perm[i];
     if (a < 0 || a >= 12 || b < 0 || b >= 12 || seen_q[a] || seen_a[b]) return misuse("wbc_create: q_perm/act_perm must be permutations of 0..11");
     seen_q[a] = seen_a[b] = true;
-    m.q_perm[i] = a;
-    m.act_perm[i] = b;
+  }
+  {
+    int qp[12], ap[12];
+    for (int i = 0; i < 12; i++) { qp[i] = model->q_perm[i]; ap[i] = model->act_perm[i]; }
+    wbc::model_set_perms(&m, qp, ap);
   }
   wbc::ParamsC P;
   wbc::params_default(kind, &P);
@@ -426,6 +499,15 @@ int wbc_stats_reset(wbc_handle h) {
   HIP_TRY(hipMemsetAsync(h->d_stats, 0, sizeof(StatsDev), h->stream));
   return 0;
 }
+
+#ifdef WBC_STAMPS
+// diagnostic build only: copies the phase stamps of the last launch (16 per block) to the host
+int wbc_debug_stamps(unsigned long long* out, int nblocks) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wbc_stamps), sizeof(unsigned long long) * 16 * nblocks));
+  return 0;
+}
+#endif
 
 int wbc_set_variant(wbc_handle h, int variant) {
   if (!h) return misuse("wbc_set_variant: null handle");

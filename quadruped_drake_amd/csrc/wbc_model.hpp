@@ -34,8 +34,16 @@ inline int model_from_flat(const double* f, ModelC* m) {
   for (int l = 0; l < 4; l++)
     for (int i = 0; i < 3; i++) m->foot_off[l][i] = f[k++];
   m->gravity = f[k++];
-  for (int i = 0; i < 12; i++) { m->q_perm[i] = i; m->act_perm[i] = i; }
+  for (int i = 0; i < 12; i++) { m->q_perm[i] = i; m->act_perm[i] = i; m->act_inv[i] = i; }
   return 0;
+}
+
+inline void model_set_perms(ModelC* m, const int* q_perm, const int* act_perm) {
+  for (int i = 0; i < 12; i++) {
+    if (q_perm) m->q_perm[i] = q_perm[i];
+    if (act_perm) m->act_perm[i] = act_perm[i];
+  }
+  for (int k = 0; k < 12; k++) m->act_inv[m->act_perm[k]] = k;
 }
 
 inline void params_default(int kind, ParamsC* p) {

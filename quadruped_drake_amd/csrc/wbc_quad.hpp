@@ -31,6 +31,8 @@ struct QuadShared {
 
 // Distributed Householder append: fold P dense rows into the upper-triangular factor.
 // Lane l holds columns 3l..3l+2: R[12][3], A[P][3]; the right-hand-side column is replicated.
+// Columns left of the pivot need no predication: their sub-diagonal part of R is zero and the
+// owner zeroes its pivot column of A after each step, so the reflection is a no-op on them.
 template <class Q, int P>
 WBC_HD void quad_qr_append(Q& qo, int l, double (*R)[3], double* rhsR, double (*A)[3], double* rhsA) {
 #pragma unroll
@@ -48,21 +50,21 @@ WBC_HD void quad_qr_append(Q& qo, int l, double (*R)[3], double* rhsR, double (*
     const double nrm = sqrt(rkk * rkk + s2);
     const double alpha = (rkk > 0.0) ? -nrm : nrm;
     const double v0 = rkk - alpha;
-    const double beta = 2.0 / (s2 + v0 * v0);
+    const double beta = 1.0 / (nrm * (nrm + fabs(rkk)));  // = 2 / (s2 + v0^2)
+    const bool own = (l == owner);
 #pragma unroll
     for (int jj = 0; jj < 3; jj++) {
-      const bool upd = (3 * l + jj) > k;
       double s = v0 * R[k][jj];
 #pragma unroll
       for (int i = 0; i < P; i++) s += col[i] * A[i][jj];
       s *= beta;
-      if (upd) {
-        R[k][jj] -= s * v0;
+      R[k][jj] -= s * v0;
 #pragma unroll
-        for (int i = 0; i < P; i++) A[i][jj] -= s * col[i];
-      }
+      for (int i = 0; i < P; i++) A[i][jj] -= s * col[i];
     }
-    if (l == owner) R[k][kk] = alpha;
+    R[k][kk] = own ? alpha : R[k][kk];
+#pragma unroll
+    for (int i = 0; i < P; i++) A[i][kk] = own ? 0.0 : A[i][kk];
     double s = v0 * rhsR[k];
 #pragma unroll
     for (int i = 0; i < P; i++) s += col[i] * rhsA[i];
@@ -268,17 +270,36 @@ template <int NR> WBC_HD double solve6(double (*Ab)[6 + NR]) {
 }
 
 // The tick.  Every lane of the quad calls this with its own Q (lane id = leg).
-// out_tau(k, x): called by lane l for actuator rows k = 3l..3l+2;  out_met: lane 0 only.
-template <class Q, int KIND, class In, class OutTau, class OutMet>
+// out_tau(row, x): lane l writes the output rows of its own three joints;  out_met: lane 0 only.
+//
+// The order of the phases is chosen for register pressure (the kernel is VGPR-bound): the leg
+// kinematics die right after the last Newton-Euler pass, the torque-map columns are built just
+// before the level-2 rows that consume them, and torques are recovered from (a_b, z_l) locally.
+// Cold per-lane storage ("stage"): values written in the leg phase and only needed again much later
+// (torque-map build, MPTC assembly, output) are parked in LDS instead of occupying registers for
+// the whole tick.  Slots in doubles.
+enum { ST_Y = 0, ST_PM = 18, ST_JL = 27, ST_JI = 36, ST_JD = 45, ST_MLL = 54, ST_MTBL = 60, ST_MTLL = 78, ST_N = 87 };
+
+// Read of a quad-shared (replicated-write) LDS value.  A volatile read (forcing a real LDS load)
+// was measured 10 % SLOWER than letting the compiler forward the stored value (profiles/r01).
+#define WBC_SH_GET(x) (x)
+template <class T> struct StageReg {  // host / register-resident fallback
+  T d[ST_N];
+  WBC_HD void put(int i, T v) { d[i] = v; }
+  WBC_HD T get(int i) const { return d[i]; }
+};
+
+template <class Q, int KIND, class KinT, class StT, class In, class OutTau, class OutMet>
 WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned mask, double mu, double mass_scale,
-                     QuadShared& sh, OutTau out_tau, OutMet out_met, int* iters_out) {
+                     KinT& K, StT& st, QuadShared& sh, OutTau out_tau, OutMet out_met, int* iters_out) {
   const int l = qo.lane();
   const bool ct = (mask >> l) & 1u;
   int status = ST_OK;
+  WBC_STAMP(0);
   // ---------------- state (replicated on the 4 lanes)
-  const double qw = in(0), qx = in(1), qy = in(2), qz = in(3);
   double R0[9];
   {
+    const double qw = in(0), qx = in(1), qy = in(2), qz = in(3);
     const double s = 2.0 / (qw * qw + qx * qx + qy * qy + qz * qz);
     R0[0] = 1.0 - s * (qy * qy + qz * qz); R0[1] = s * (qx * qy - qw * qz); R0[2] = s * (qx * qz + qw * qy);
     R0[3] = s * (qx * qy + qw * qz); R0[4] = 1.0 - s * (qx * qx + qz * qz); R0[5] = s * (qy * qz - qw * qx);
@@ -296,76 +317,181 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
     rot_inertia(R0, m.base_I, bI);
     for (int i = 0; i < 6; i++) bI[i] *= mass_scale;
   }
-  double hb[6];
+  // task-space errors of the body (both laws)
+  double rpy[3], E[9], rpyd[3];
   {
-    double t2[3], t3[3], Iw_w[3], t4[3];
-    const double g3[3] = {0.0, 0.0, gz};
-    cross(w0, bmc, t2);
-    cross(w0, t2, t2);
-    symv(bI, w0, Iw_w);
-    cross(w0, Iw_w, t3);
-    cross(bmc, g3, t4);
-    for (int i = 0; i < 3; i++) { hb[i] = t3[i] + t4[i]; hb[3 + i] = bm * g3[i] + t2[i]; }
+    rpy[0] = atan2(R0[7], R0[8]);
+    rpy[1] = atan2(-R0[6], sqrt(R0[0] * R0[0] + R0[3] * R0[3]));
+    rpy[2] = atan2(R0[3], R0[0]);
+    // sin/cos of pitch and yaw straight from R0 = Rz(y) Ry(p) Rx(r): no trig calls needed
+    const double cp = sqrt(R0[0] * R0[0] + R0[3] * R0[3]), sp = -R0[6];
+    const double icp = 1.0 / cp;
+    const double cy = R0[0] * icp, sy = R0[3] * icp;
+    E[0] = cp * cy; E[1] = -sy; E[2] = 0.0; E[3] = cp * sy; E[4] = cy; E[5] = 0.0; E[6] = -sp; E[7] = 0.0; E[8] = 1.0;
+    const double Ei[9] = {cy * icp, sy * icp, 0.0, -sy, cy, 0.0, cy * sp * icp, sy * sp * icp, 1.0};
+    rotv(Ei, w0, rpyd);
   }
-  // ---------------- own leg (lane-local)
-  LegKin<double> K;
-  LegDyn<double> D;
-  double qd[3];
+  double xt_b[6], xdt_b[6], xdd_b[6], ades[6];
   {
-    double sn[3], cs[3];
-    for (int k = 0; k < 3; k++) {
-      const int row = m.q_perm[3 * l + k];
-      const double th = in(7 + row);
-      sn[k] = sin(th); cs[k] = cos(th);
-      qd[k] = in(25 + row);
+    double tg_pb[3], tg_pdb[3], tg_pddb[3], tg_rpy[3], tg_rpyd[3], tg_rpydd[3];
+    for (int i = 0; i < 3; i++) {
+      tg_pb[i] = in(37 + i); tg_pdb[i] = in(40 + i); tg_pddb[i] = in(43 + i);
+      tg_rpy[i] = in(46 + i); tg_rpyd[i] = in(49 + i); tg_rpydd[i] = in(52 + i);
     }
-    leg_fk(m, l, R0, sn, cs, K);
+    for (int i = 0; i < 3; i++) { xt_b[i] = rpy[i] - tg_rpy[i]; xt_b[3 + i] = p0[i] - tg_pb[i]; }
+    if (KIND == KIND_ID) {
+      double rpydd_des[3], od[3];
+      for (int i = 0; i < 3; i++) {
+        ades[3 + i] = tg_pddb[i] - P.Kp_body_p * xt_b[3 + i] - P.Kd_body_p * (v0[i] - tg_pdb[i]);
+        rpydd_des[i] = tg_rpydd[i] - P.Kp_body_rpy * xt_b[i] - P.Kd_body_rpy * (rpyd[i] - tg_rpyd[i]);
+      }
+      rotv(E, rpydd_des, od);
+      for (int i = 0; i < 3; i++) { ades[i] = od[i]; xdt_b[i] = 0.0; xdt_b[3 + i] = 0.0; xdd_b[i] = 0.0; xdd_b[3 + i] = 0.0; }
+    } else {
+      double om_rt[3], xdn[3], xddn[3];
+      rotv(E, rpyd, om_rt);      // literal E(rpy) * rpyd round trip of mptc_controller.py:245
+      rotv(E, tg_rpyd, xdn);
+      rotv(E, tg_rpydd, xddn);
+      for (int i = 0; i < 3; i++) {
+        xdt_b[i] = om_rt[i] - xdn[i];
+        xdt_b[3 + i] = v0[i] - tg_pdb[i];
+        xdd_b[i] = xddn[i];
+        xdd_b[3 + i] = tg_pddb[i];
+        ades[i] = 0.0; ades[3 + i] = 0.0;
+      }
+    }
   }
+  WBC_STAMP(1);
+  // ---------------- own leg: FK, Newton-Euler bias pass, composite inertia, foot Jacobian
+  double rf[3], Jdv[3], pd[3], rd[3], hl[3];
+  double X[18];
+  double hbN[6];                 // own leg's reaction wrench at the base origin
+  double t0l[3];                 // own rows of t0 without the Y ab0 part: hl + ct Pm bc
   double lm = 0.0, lh[3] = {0.0, 0.0, 0.0}, lI[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double Cb_leg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, Cl[3] = {0.0, 0.0, 0.0}, xi[3] = {0.0, 0.0, 0.0};
+  double xt_s[3], xdt_s[3], xdd_s[3];
   {
-    double Nb[3], Fb[3];
-    leg_rnea<double, true>(m, l, K, w0, qd, gz, D.hl, Nb, Fb, &D);
-    for (int i = 0; i < 3; i++) { hb[i] += qo.sum(Nb[i]); hb[3 + i] += qo.sum(Fb[i]); }
-    leg_crba(m, l, K, D, lm, lh, lI);
-    for (int k = 0; k < 3; k++) {
-      const double d[3] = {K.rf[0] - K.r[k][0], K.rf[1] - K.r[k][1], K.rf[2] - K.r[k][2]};
-      double c[3];
-      cross(K.ax[k], d, c);
-      for (int i = 0; i < 3; i++) D.Jl[3 * i + k] = c[i];
+    LegDyn<double> D;
+    double qd[3];
+    double Jl[9], Ji[9], Y[18], Pm[9];
+    {
+      double sn[3], cs[3];
+      for (int k = 0; k < 3; k++) {
+        const int row = m.q_perm[3 * l + k];
+        const double th = in(7 + row);
+        wbc_sincos(th, sn[k], cs[k]);
+        qd[k] = in(25 + row);
+      }
+      leg_fk(m, l, R0, sn, cs, K);
     }
-    const double det = inv3(D.Jl, D.Ji);
+    WBC_STAMP(2);
+    {
+      const KinT& Kc = K;
+      leg_rnea<double, true>(m, l, Kc, w0, qd, gz, hl, hbN, hbN + 3, &D);
+      leg_crba(m, l, Kc, D, lm, lh, lI);
+    }
+    WBC_STAMP(3);
+    for (int i = 0; i < 3; i++) { rf[i] = K.rf(i); Jdv[i] = D.Jdv[i]; rd[i] = D.rd[i]; pd[i] = v0[i] + D.rd[i]; }
+    for (int i = 0; i < 9; i++) st.put(ST_JD + i, D.Jd[i]);
+    for (int k = 0; k < 3; k++) {
+      const double d[3] = {rf[0] - K.r(k, 0), rf[1] - K.r(k, 1), rf[2] - K.r(k, 2)};
+      const double axv[3] = {K.ax(k, 0), K.ax(k, 1), K.ax(k, 2)};
+      double c[3];
+      cross(axv, d, c);
+      for (int i = 0; i < 3; i++) Jl[3 * i + k] = c[i];
+    }
+    const double det = inv3(Jl, Ji);
     if (qo.any(!(fabs(det) > 1e-12))) status = ST_SINGULAR;
-    for (int i = 0; i < 3; i++) D.pd[i] = v0[i] + D.rd[i];
-  }
-  const double Mc = bm + qo.sum(lm);
-  double Hc[3], Ic[6];
-  for (int i = 0; i < 3; i++) Hc[i] = bmc[i] + qo.sum(lh[i]);
-  for (int i = 0; i < 6; i++) Ic[i] = bI[i] + qo.sum(lI[i]);
-
-  // ---------------- per-leg reductions
-  const double* r = K.rf;
-  double X[18], Pm[9], Y[18], bc[3];
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < 3; j++)
-      X[3 * i + j] = D.Mbl[3 * i] * D.Ji[j] + D.Mbl[3 * i + 1] * D.Ji[3 + j] + D.Mbl[3 * i + 2] * D.Ji[6 + j];
-  {
     double Mf[9];
     sym_to_full(D.Mll, Mf);
-    mm3(Mf, D.Ji, Pm);
-  }
-  for (int i = 0; i < 3; i++) {
-    const double a0 = Pm[3 * i], a1 = Pm[3 * i + 1], a2 = Pm[3 * i + 2];
-    Y[6 * i + 0] = D.Mbl[0 * 3 + i] + (a1 * r[2] - a2 * r[1]);
-    Y[6 * i + 1] = D.Mbl[1 * 3 + i] + (a2 * r[0] - a0 * r[2]);
-    Y[6 * i + 2] = D.Mbl[2 * 3 + i] + (a0 * r[1] - a1 * r[0]);
-    Y[6 * i + 3] = D.Mbl[3 * 3 + i] - a0;
-    Y[6 * i + 4] = D.Mbl[4 * 3 + i] - a1;
-    Y[6 * i + 5] = D.Mbl[5 * 3 + i] - a2;
-    bc[i] = ct ? (-P.Kd_contact * D.pd[i] - D.Jdv[i]) : 0.0;
-  }
-  // G_b = Mbb + sum_l [X [r]x, -X] ;  k = hb + sum_ct X bc
-  double Gs[6][6];
+    mm3(Mf, Ji, Pm);  // Pm = Mll Ji
+    // own foot targets / errors (zero for a contact leg)
+    for (int i = 0; i < 3; i++) {
+      const double pf = p0[i] + rf[i];
+      const double tp = in(37 + 18 + 9 * l + i), tpd = in(37 + 21 + 9 * l + i), tpdd = in(37 + 24 + 9 * l + i);
+      xt_s[i] = ct ? 0.0 : pf - tp;
+      xdt_s[i] = ct ? 0.0 : pd[i] - tpd;
+      xdd_s[i] = ct ? 0.0 : tpdd;
+    }
+    if (KIND == KIND_MPTC) {
+      // xi = Jbar xd_tilde on the own joints.  Contact leg: xi = -Mll^-1 (Y xdt_b) - Ji Jfb xdt_b
+      // with Y xdt_b = Mbl' xdt_b - Pm (Jfb xdt_b), so neither Y nor Mll^-1 Y is needed yet.
+      double Mli[9];
+      inv3(Mf, Mli);
+      double t[3], jfb[3];
+      cross(xdt_b, rf, t);
+      for (int i = 0; i < 3; i++) jfb[i] = xdt_b[3 + i] + t[i];
+      if (ct) {
+        double yx[3];
+        for (int i = 0; i < 3; i++) {
+          double s = 0.0;
+          for (int j = 0; j < 6; j++) s += D.Mbl[3 * j + i] * xdt_b[j];
+          yx[i] = s - (Pm[3 * i] * jfb[0] + Pm[3 * i + 1] * jfb[1] + Pm[3 * i + 2] * jfb[2]);
+        }
+        for (int i = 0; i < 3; i++)
+          xi[i] = -(Mli[3 * i] * yx[0] + Mli[3 * i + 1] * yx[1] + Mli[3 * i + 2] * yx[2]) -
+                  (Ji[3 * i] * jfb[0] + Ji[3 * i + 1] * jfb[1] + Ji[3 * i + 2] * jfb[2]);
+      } else {
+        const double y[3] = {xdt_s[0] - jfb[0], xdt_s[1] - jfb[1], xdt_s[2] - jfb[2]};
+        rotv(Ji, y, xi);
+      }
+      // C xi = 1/4 [h(v + xi) - h(v - xi)]  (two more Newton-Euler passes over the cached kinematics)
+      const KinT& Kc = K;
+      for (int sgi = 0; sgi < 2; sgi++) {
+        const double sg = sgi ? -0.25 : 0.25, s1 = sgi ? -1.0 : 1.0;
+        const double wv[3] = {w0[0] + s1 * xdt_b[0], w0[1] + s1 * xdt_b[1], w0[2] + s1 * xdt_b[2]};
+        const double qv[3] = {qd[0] + s1 * xi[0], qd[1] + s1 * xi[1], qd[2] + s1 * xi[2]};
+        double hl2[3], Nb[3], Fb[3];
+        leg_rnea<double, false>(m, l, Kc, wv, qv, 0.0, hl2, Nb, Fb, (LegDyn<double>*)nullptr);
+        for (int i = 0; i < 3; i++) { Cb_leg[i] += sg * Nb[i]; Cb_leg[3 + i] += sg * Fb[i]; Cl[i] += sg * hl2[i]; }
+      }
+    }
+    WBC_STAMP(4);
+    // X = Mbl Ji, Y = Mbl' - Pm Jfb
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 3; j++)
+        X[3 * i + j] = D.Mbl[3 * i] * Ji[j] + D.Mbl[3 * i + 1] * Ji[3 + j] + D.Mbl[3 * i + 2] * Ji[6 + j];
+    for (int i = 0; i < 3; i++) {
+      const double a0 = Pm[3 * i], a1 = Pm[3 * i + 1], a2 = Pm[3 * i + 2];
+      Y[6 * i + 0] = D.Mbl[0 * 3 + i] + (a1 * rf[2] - a2 * rf[1]);
+      Y[6 * i + 1] = D.Mbl[1 * 3 + i] + (a2 * rf[0] - a0 * rf[2]);
+      Y[6 * i + 2] = D.Mbl[2 * 3 + i] + (a0 * rf[1] - a1 * rf[0]);
+      Y[6 * i + 3] = D.Mbl[3 * 3 + i] - a0;
+      Y[6 * i + 4] = D.Mbl[4 * 3 + i] - a1;
+      Y[6 * i + 5] = D.Mbl[5 * 3 + i] - a2;
+    }
+    for (int i = 0; i < 18; i++) st.put(ST_Y + i, Y[i]);
+    for (int i = 0; i < 9; i++) { st.put(ST_PM + i, Pm[i]); st.put(ST_JL + i, Jl[i]); st.put(ST_JI + i, Ji[i]); }
+    for (int i = 0; i < 6; i++) st.put(ST_MLL + i, D.Mll[i]);
+    for (int i = 0; i < 3; i++) {
+      const double b0 = ct ? (-P.Kd_contact * pd[0] - Jdv[0]) : 0.0, b1 = ct ? (-P.Kd_contact * pd[1] - Jdv[1]) : 0.0,
+                   b2 = ct ? (-P.Kd_contact * pd[2] - Jdv[2]) : 0.0;
+      t0l[i] = hl[i] + (Pm[3 * i] * b0 + Pm[3 * i + 1] * b1 + Pm[3 * i + 2] * b2);
+    }
+  }  // D dead; K (the kinematics arena) is not read again: its storage may alias `sh`
+  const double bc[3] = {ct ? (-P.Kd_contact * pd[0] - Jdv[0]) : 0.0, ct ? (-P.Kd_contact * pd[1] - Jdv[1]) : 0.0,
+                        ct ? (-P.Kd_contact * pd[2] - Jdv[2]) : 0.0};
+  WBC_STAMP(5);
+  // ---------------- base: bias wrench, composite inertia -> Gs = G_b, kv
+  double Gs[6][6], kv[6];
   {
+    double hb[6];
+    {
+      double t2[3], t3[3], Iw_w[3], t4[3];
+      const double g3[3] = {0.0, 0.0, gz};
+      cross(w0, bmc, t2);
+      cross(w0, t2, t2);
+      symv(bI, w0, Iw_w);
+      cross(w0, Iw_w, t3);
+      cross(bmc, g3, t4);
+      for (int i = 0; i < 3; i++) { hb[i] = t3[i] + t4[i]; hb[3 + i] = bm * g3[i] + t2[i]; }
+    }
+    for (int i = 0; i < 6; i++)
+      kv[i] = hb[i] + qo.sum(hbN[i] + (ct ? (X[3 * i] * bc[0] + X[3 * i + 1] * bc[1] + X[3 * i + 2] * bc[2]) : 0.0));
+    const double Mc = bm + qo.sum(lm);
+    double Hc[3], Ic[6];
+    for (int i = 0; i < 3; i++) Hc[i] = bmc[i] + qo.sum(lh[i]);
+    for (int i = 0; i < 6; i++) Ic[i] = bI[i] + qo.sum(lI[i]);
     double Mbb[6][6];
     for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Mbb[i][j] = 0.0;
     Mbb[0][0] = Ic[0]; Mbb[1][1] = Ic[1]; Mbb[2][2] = Ic[2];
@@ -377,17 +503,15 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
     Mbb[3][3] = Mc; Mbb[4][4] = Mc; Mbb[5][5] = Mc;
     for (int i = 0; i < 6; i++) {
       const double a0 = X[3 * i], a1 = X[3 * i + 1], a2 = X[3 * i + 2];
-      Gs[i][0] = Mbb[i][0] + qo.sum(a1 * r[2] - a2 * r[1]);
-      Gs[i][1] = Mbb[i][1] + qo.sum(a2 * r[0] - a0 * r[2]);
-      Gs[i][2] = Mbb[i][2] + qo.sum(a0 * r[1] - a1 * r[0]);
+      Gs[i][0] = Mbb[i][0] + qo.sum(a1 * rf[2] - a2 * rf[1]);
+      Gs[i][1] = Mbb[i][1] + qo.sum(a2 * rf[0] - a0 * rf[2]);
+      Gs[i][2] = Mbb[i][2] + qo.sum(a0 * rf[1] - a1 * rf[0]);
       Gs[i][3] = Mbb[i][3] - qo.sum(a0);
       Gs[i][4] = Mbb[i][4] - qo.sum(a1);
       Gs[i][5] = Mbb[i][5] - qo.sum(a2);
     }
   }
-  double kv[6];
-  for (int i = 0; i < 6; i++)
-    kv[i] = hb[i] + qo.sum(ct ? (X[3 * i] * bc[0] + X[3 * i + 1] * bc[1] + X[3 * i + 2] * bc[2]) : 0.0);
+  WBC_STAMP(6);
   // own columns of B and ab0:  G_b [B_l | ab0] = [W_l or -X_l | -k]
   double B[6][3], ab0[6];
   {
@@ -397,202 +521,109 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
       Ab[i][9] = -kv[i];
     }
     for (int j = 0; j < 3; j++) {
-      double col[6];
-      if (ct) {
-        const double e[3] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0};
-        double c[3];
-        cross(r, e, c);
-        col[0] = c[0]; col[1] = c[1]; col[2] = c[2]; col[3] = e[0]; col[4] = e[1]; col[5] = e[2];
-      } else {
-        for (int i = 0; i < 6; i++) col[i] = -X[3 * i + j];
+      const double e[3] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0};
+      double c[3];
+      cross(rf, e, c);
+      for (int i = 0; i < 3; i++) {
+        Ab[i][6 + j] = ct ? c[i] : -X[3 * i + j];
+        Ab[3 + i][6 + j] = ct ? e[i] : -X[3 * (3 + i) + j];
       }
-      for (int i = 0; i < 6; i++) Ab[i][6 + j] = col[i];
     }
     const double rc = solve6<4>(Ab);
     if (!(rc > 1e-12)) status = ST_SINGULAR;
     for (int i = 0; i < 6; i++) { B[i][0] = Ab[i][6]; B[i][1] = Ab[i][7]; B[i][2] = Ab[i][8]; ab0[i] = Ab[i][9]; }
   }
-  // torque map, own COLUMNS: Tc[l'][i][j] = (Y_l' B_l)[i][j] + delta_{l l'} D_l[i][j];  t0 replicated
-  double Tc[4][3][3], t0[NZ];
-  {
-    double t0l[3];
-    for (int i = 0; i < 3; i++) {
-      double s = D.hl[i];
-      for (int j = 0; j < 6; j++) s += Y[6 * i + j] * ab0[j];
-      if (ct) s += Pm[3 * i] * bc[0] + Pm[3 * i + 1] * bc[1] + Pm[3 * i + 2] * bc[2];
-      t0l[i] = s;
-    }
-#pragma unroll
-    for (int lp = 0; lp < 4; lp++) {
-      double Yp[18];
-#pragma unroll
-      for (int i = 0; i < 18; i++) Yp[i] = qo.bcast_s(Y[i], lp);
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        t0[3 * lp + i] = qo.bcast_s(t0l[i], lp);
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-          double s = 0.0;
-#pragma unroll
-          for (int k = 0; k < 6; k++) s += Yp[6 * i + k] * B[k][j];
-          if (lp == l) s += ct ? -D.Jl[3 * j + i] : Pm[3 * i + j];
-          Tc[lp][i][j] = s;
-        }
-      }
-    }
-  }
 
+  WBC_STAMP(7);
   // ---------------- level-1 rows
   const double eps = sqrt(P.eps2);
-  double Rc[NZ][3], rhsR[NZ];
   const double sw_b = sqrt(P.w_body), sw_f = sqrt(P.w_foot);
-  double rpy[3], E[9], Ei[9];
-  {
-    rpy[0] = atan2(R0[7], R0[8]);
-    rpy[1] = atan2(-R0[6], sqrt(R0[0] * R0[0] + R0[3] * R0[3]));
-    rpy[2] = atan2(R0[3], R0[0]);
-    const double sp = sin(rpy[1]), cp = cos(rpy[1]), sy = sin(rpy[2]), cy = cos(rpy[2]);
-    E[0] = cp * cy; E[1] = -sy; E[2] = 0.0; E[3] = cp * sy; E[4] = cy; E[5] = 0.0; E[6] = -sp; E[7] = 0.0; E[8] = 1.0;
-    const double icp = 1.0 / cp;
-    Ei[0] = cy * icp; Ei[1] = sy * icp; Ei[2] = 0.0; Ei[3] = -sy; Ei[4] = cy; Ei[5] = 0.0;
-    Ei[6] = cy * sp * icp; Ei[7] = sy * sp * icp; Ei[8] = 1.0;
-  }
-  double rpyd[3];
-  rotv(Ei, w0, rpyd);
-  double tg_pb[3], tg_pdb[3], tg_pddb[3], tg_rpy[3], tg_rpyd[3], tg_rpydd[3];
-  for (int i = 0; i < 3; i++) {
-    tg_pb[i] = in(37 + i); tg_pdb[i] = in(40 + i); tg_pddb[i] = in(43 + i);
-    tg_rpy[i] = in(46 + i); tg_rpyd[i] = in(49 + i); tg_rpydd[i] = in(52 + i);
-  }
-  // own foot targets / errors (zero for a contact leg)
-  double xt_s[3], xdt_s[3], xdd_s[3];
-  for (int i = 0; i < 3; i++) {
-    const double pf = p0[i] + K.rf[i];
-    const double tp = in(37 + 18 + 9 * l + i), tpd = in(37 + 21 + 9 * l + i), tpdd = in(37 + 24 + 9 * l + i);
-    xt_s[i] = ct ? 0.0 : pf - tp;
-    xdt_s[i] = ct ? 0.0 : D.pd[i] - tpd;
-    xdd_s[i] = ct ? 0.0 : tpdd;
-  }
-  double xt_b[6], xdt_b[6];
-  for (int i = 0; i < 3; i++) { xt_b[i] = rpy[i] - tg_rpy[i]; xt_b[3 + i] = p0[i] - tg_pb[i]; }
+  double Rc[NZ][3], rhsR[NZ];
   double met_err = 0.0;
   for (int i = 0; i < 6; i++) met_err += xt_b[i] * xt_b[i];
   met_err += qo.sum(xt_s[0] * xt_s[0] + xt_s[1] * xt_s[1] + xt_s[2] * xt_s[2]);
   double met_V = 0.0, met_Vdot = 0.0;
   double vrow[3] = {0.0, 0.0, 0.0}, vconst = 0.0;  // Vdot += vconst + sum_l vrow_l . z_l
-
-  // diagonal rows: swing leg sqrt(w_foot) (ID) / 0 (MPTC); contact leg eps
-  double dval[3], drhs[3];
-  for (int i = 0; i < 3; i++) {
-    if (ct) { dval[i] = eps; drhs[i] = 0.0; }
-    else if (KIND == KIND_ID) {
-      const double des = xdd_s[i] - P.Kp_foot * xt_s[i] - P.Kd_foot * xdt_s[i];
-      dval[i] = sw_f; drhs[i] = sw_f * (des - D.Jdv[i]);
-    } else { dval[i] = 0.0; drhs[i] = 0.0; }
-  }
-#pragma unroll
-  for (int k = 0; k < NZ; k++)
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++) Rc[k][jj] = (k == 3 * l + jj) ? dval[jj] : 0.0;
-#pragma unroll
-  for (int lp = 0; lp < 4; lp++)
-#pragma unroll
-    for (int i = 0; i < 3; i++) rhsR[3 * lp + i] = qo.bcast_s(drhs[i], lp);
-
-  double blk[6][3], brhs[6];
-  if (KIND == KIND_ID) {
-    double rpydd_des[3], od[3], ades[6];
+  {
+    // diagonal rows: swing leg sqrt(w_foot) (ID) / 0 (MPTC); contact leg eps
+    double dval[3], drhs[3];
     for (int i = 0; i < 3; i++) {
-      ades[3 + i] = tg_pddb[i] - P.Kp_body_p * (p0[i] - tg_pb[i]) - P.Kd_body_p * (v0[i] - tg_pdb[i]);
-      rpydd_des[i] = tg_rpydd[i] - P.Kp_body_rpy * (rpy[i] - tg_rpy[i]) - P.Kd_body_rpy * (rpyd[i] - tg_rpyd[i]);
+      if (ct) { dval[i] = eps; drhs[i] = 0.0; }
+      else if (KIND == KIND_ID) {
+        const double des = xdd_s[i] - P.Kp_foot * xt_s[i] - P.Kd_foot * xdt_s[i];
+        dval[i] = sw_f; drhs[i] = sw_f * (des - Jdv[i]);
+      } else { dval[i] = 0.0; drhs[i] = 0.0; }
     }
-    rotv(E, rpydd_des, od);
-    for (int i = 0; i < 3; i++) ades[i] = od[i];
+#pragma unroll
+    for (int k = 0; k < NZ; k++)
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++) Rc[k][jj] = (k == 3 * l + jj) ? dval[jj] : 0.0;
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++)
+#pragma unroll
+      for (int i = 0; i < 3; i++) rhsR[3 * lp + i] = qo.bcast_s(drhs[i], lp);
+  }
+  if (KIND == KIND_ID) {
+    double blk[6][3], brhs[6];
     for (int i = 0; i < 6; i++) {
       for (int j = 0; j < 3; j++) blk[i][j] = sw_b * B[i][j];
       brhs[i] = sw_b * (ades[i] - ab0[i]);
     }
     quad_qr_append<Q, 6>(qo, l, Rc, rhsR, blk, brhs);
   } else {
-    // ---- MPTC in task coordinates (see wbc_tick.hpp for the derivation)
-    double A[18];  // Ji Jfb
-    for (int i = 0; i < 3; i++) {
-      const double a0 = D.Ji[3 * i], a1 = D.Ji[3 * i + 1], a2 = D.Ji[3 * i + 2];
-      A[6 * i + 0] = -(a1 * r[2] - a2 * r[1]);
-      A[6 * i + 1] = -(a2 * r[0] - a0 * r[2]);
-      A[6 * i + 2] = -(a0 * r[1] - a1 * r[0]);
-      A[6 * i + 3] = a0; A[6 * i + 4] = a1; A[6 * i + 5] = a2;
-    }
-    double Mt_bl[18], Mt_ll[9], Mli[9], MiY[18];
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 6; j++) Mt_bl[3 * j + i] = D.Ji[i] * Y[j] + D.Ji[3 + i] * Y[6 + j] + D.Ji[6 + i] * Y[12 + j];
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 3; j++) Mt_ll[3 * i + j] = D.Ji[i] * Pm[j] + D.Ji[3 + i] * Pm[3 + j] + D.Ji[6 + i] * Pm[6 + j];
-    {
-      double Mf[9];
-      sym_to_full(D.Mll, Mf);
-      inv3(Mf, Mli);
-    }
-    for (int i = 0; i < 3; i++)
-      for (int j = 0; j < 6; j++) MiY[6 * i + j] = Mli[3 * i] * Y[j] + Mli[3 * i + 1] * Y[6 + j] + Mli[3 * i + 2] * Y[12 + j];
-    double Lbb[6][6];
-    for (int i = 0; i < 6; i++)
-      for (int j = 0; j < 6; j++) {
-        double c = A[i] * Y[j] + A[6 + i] * Y[6 + j] + A[12 + i] * Y[12 + j];
-        if (ct) c += Y[i] * MiY[j] + Y[6 + i] * MiY[6 + j] + Y[12 + i] * MiY[12 + j];
-        Lbb[i][j] = Gs[i][j] - qo.sum(c);
-      }
-    double om_rt[3], xdn[3], xddn[3], xdd_b[6];
-    rotv(E, rpyd, om_rt);
-    rotv(E, tg_rpyd, xdn);
-    rotv(E, tg_rpydd, xddn);
-    for (int i = 0; i < 3; i++) {
-      xdt_b[i] = om_rt[i] - xdn[i];
-      xdt_b[3 + i] = v0[i] - tg_pdb[i];
-      xdd_b[i] = xddn[i];
-      xdd_b[3 + i] = tg_pddb[i];
-    }
-    // xi (own joints)
-    double xi[3];
-    {
-      double t[3], jfb[3];
-      cross(xdt_b, r, t);
-      for (int i = 0; i < 3; i++) jfb[i] = xdt_b[3 + i] + t[i];
-      if (ct) {
-        for (int i = 0; i < 3; i++) {
-          double s = 0.0;
-          for (int j = 0; j < 6; j++) s += MiY[6 * i + j] * xdt_b[j];
-          xi[i] = -s - (D.Ji[3 * i] * jfb[0] + D.Ji[3 * i + 1] * jfb[1] + D.Ji[3 * i + 2] * jfb[2]);
-        }
-      } else {
-        const double y[3] = {xdt_s[0] - jfb[0], xdt_s[1] - jfb[1], xdt_s[2] - jfb[2]};
-        rotv(D.Ji, y, xi);
-      }
-    }
-    // C xi = 1/4 [h(v + xi) - h(v - xi)]
-    double Cb_base[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, Cb_leg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, Cl[3] = {0.0, 0.0, 0.0};
-    for (int sgi = 0; sgi < 2; sgi++) {
-      const double sg = sgi ? -0.25 : 0.25;
-      const double wv[3] = {w0[0] + (sgi ? -1.0 : 1.0) * xdt_b[0], w0[1] + (sgi ? -1.0 : 1.0) * xdt_b[1],
-                            w0[2] + (sgi ? -1.0 : 1.0) * xdt_b[2]};
-      double t2[3], t3[3], Iw_w[3];
-      cross(wv, bmc, t2);
-      cross(wv, t2, t2);
-      symv(bI, wv, Iw_w);
-      cross(wv, Iw_w, t3);
-      for (int i = 0; i < 3; i++) { Cb_base[i] += sg * t3[i]; Cb_base[3 + i] += sg * t2[i]; }
-      const double qv[3] = {qd[0] + (sgi ? -1.0 : 1.0) * xi[0], qd[1] + (sgi ? -1.0 : 1.0) * xi[1],
-                            qd[2] + (sgi ? -1.0 : 1.0) * xi[2]};
-      double hl2[3], Nb[3], Fb[3];
-      leg_rnea<double, false>(m, l, K, wv, qv, 0.0, hl2, Nb, Fb, (LegDyn<double>*)nullptr);
-      for (int i = 0; i < 3; i++) { Cb_leg[i] += sg * Nb[i]; Cb_leg[3 + i] += sg * Fb[i]; Cl[i] += sg * hl2[i]; }
-    }
-    // Lambda (J Minv C xi): base rows replicated, own swing rows local
+    // ---- MPTC in task coordinates (derivation: wbc_tick.hpp / DESIGN.md)
+    // Register diet: Lambda_bb (replicated 6x6) is parked in the quad-shared LDS block (it aliases
+    // the active-set factor, which is not live yet), Mt_bl / Mt_ll in the per-lane stage.
+    double* Lsh = &sh.Rq[0][0];
     double LJ_b[6], LJ_s[3];
     {
+      double Y[18], Ji[9], MiY[18];
+      for (int i = 0; i < 18; i++) Y[i] = st.get(ST_Y + i);
+      for (int i = 0; i < 9; i++) Ji[i] = st.get(ST_JI + i);
+      {
+        double Ms[6], Mf[9], Mli[9];
+        for (int i = 0; i < 6; i++) Ms[i] = st.get(ST_MLL + i);
+        sym_to_full(Ms, Mf);
+        inv3(Mf, Mli);
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 6; j++) MiY[6 * i + j] = Mli[3 * i] * Y[j] + Mli[3 * i + 1] * Y[6 + j] + Mli[3 * i + 2] * Y[12 + j];
+      }
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 6; j++) st.put(ST_MTBL + 3 * j + i, Ji[i] * Y[j] + Ji[3 + i] * Y[6 + j] + Ji[6 + i] * Y[12 + j]);
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+          st.put(ST_MTLL + 3 * i + j, Ji[i] * st.get(ST_PM + j) + Ji[3 + i] * st.get(ST_PM + 3 + j) + Ji[6 + i] * st.get(ST_PM + 6 + j));
+      {
+        double A[18];  // Ji Jfb
+        for (int i = 0; i < 3; i++) {
+          const double a0 = Ji[3 * i], a1 = Ji[3 * i + 1], a2 = Ji[3 * i + 2];
+          A[6 * i + 0] = -(a1 * rf[2] - a2 * rf[1]);
+          A[6 * i + 1] = -(a2 * rf[0] - a0 * rf[2]);
+          A[6 * i + 2] = -(a0 * rf[1] - a1 * rf[0]);
+          A[6 * i + 3] = a0; A[6 * i + 4] = a1; A[6 * i + 5] = a2;
+        }
+        for (int i = 0; i < 6; i++)
+          for (int j = 0; j < 6; j++) {
+            double c = A[i] * Y[j] + A[6 + i] * Y[6 + j] + A[12 + i] * Y[12 + j];
+            if (ct) c += Y[i] * MiY[j] + Y[6 + i] * MiY[6 + j] + Y[12 + i] * MiY[12 + j];
+            Lsh[6 * i + j] = Gs[i][j] - qo.sum(c);
+          }
+      }
+      // Lambda (J Minv C xi): base rows replicated, own swing rows local
+      double Cb_base[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      for (int sgi = 0; sgi < 2; sgi++) {
+        const double sg = sgi ? -0.25 : 0.25, s1 = sgi ? -1.0 : 1.0;
+        const double wv[3] = {w0[0] + s1 * xdt_b[0], w0[1] + s1 * xdt_b[1], w0[2] + s1 * xdt_b[2]};
+        double t2[3], t3[3], Iw_w[3];
+        cross(wv, bmc, t2);
+        cross(wv, t2, t2);
+        symv(bI, wv, Iw_w);
+        cross(wv, Iw_w, t3);
+        for (int i = 0; i < 3; i++) { Cb_base[i] += sg * t3[i]; Cb_base[3 + i] += sg * t2[i]; }
+      }
       double gl[3], c[3];
-      for (int i = 0; i < 3; i++) gl[i] = D.Ji[i] * Cl[0] + D.Ji[3 + i] * Cl[1] + D.Ji[6 + i] * Cl[2];
-      cross(r, gl, c);
+      for (int i = 0; i < 3; i++) gl[i] = Ji[i] * Cl[0] + Ji[3 + i] * Cl[1] + Ji[6 + i] * Cl[2];
+      cross(rf, gl, c);
       for (int j = 0; j < 6; j++) {
         double loc = Cb_leg[j] - ((j < 3) ? c[j] : gl[j - 3]);
         if (ct) loc -= MiY[j] * Cl[0] + MiY[6 + j] * Cl[1] + MiY[12 + j] * Cl[2];
@@ -603,34 +634,35 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
     double s1_s[3];
     {
       double t[3];
-      cross(xdt_b, D.rd, t);
+      cross(xdt_b, rd, t);
       for (int i = 0; i < 3; i++) {
-        const double jx = t[i] + D.Jd[3 * i] * xi[0] + D.Jd[3 * i + 1] * xi[1] + D.Jd[3 * i + 2] * xi[2];
-        s1_s[i] = ct ? 0.0 : xdd_s[i] - D.Jdv[i] + jx;
+        const double jx = t[i] + st.get(ST_JD + 3 * i) * xi[0] + st.get(ST_JD + 3 * i + 1) * xi[1] + st.get(ST_JD + 3 * i + 2) * xi[2];
+        s1_s[i] = ct ? 0.0 : xdd_s[i] - Jdv[i] + jx;
       }
     }
     auto lam_mul = [&](const double* yb, const double* ys, double* ob, double* os) {
       for (int i = 0; i < 6; i++) {
         double s = 0.0;
-        for (int j = 0; j < 6; j++) s += Lbb[i][j] * yb[j];
-        const double loc = ct ? 0.0 : Mt_bl[3 * i] * ys[0] + Mt_bl[3 * i + 1] * ys[1] + Mt_bl[3 * i + 2] * ys[2];
+        for (int j = 0; j < 6; j++) s += WBC_SH_GET(Lsh[6 * i + j]) * yb[j];
+        const double loc = ct ? 0.0 : st.get(ST_MTBL + 3 * i) * ys[0] + st.get(ST_MTBL + 3 * i + 1) * ys[1] + st.get(ST_MTBL + 3 * i + 2) * ys[2];
         ob[i] = s + qo.sum(loc);
       }
       for (int i = 0; i < 3; i++) {
-        double s = Mt_ll[3 * i] * ys[0] + Mt_ll[3 * i + 1] * ys[1] + Mt_ll[3 * i + 2] * ys[2];
-        for (int j = 0; j < 6; j++) s += Mt_bl[3 * j + i] * yb[j];
+        double s = st.get(ST_MTLL + 3 * i) * ys[0] + st.get(ST_MTLL + 3 * i + 1) * ys[1] + st.get(ST_MTLL + 3 * i + 2) * ys[2];
+        for (int j = 0; j < 6; j++) s += st.get(ST_MTBL + 3 * j + i) * yb[j];
         os[i] = ct ? 0.0 : s;
       }
     };
-    double Ls_b[6], Ls_s[3], c1_b[6], c1_s[3];
-    lam_mul(xdd_b, s1_s, Ls_b, Ls_s);
-    for (int i = 0; i < 6; i++) {
-      const double kp = (i < 3) ? P.Kp_body_rpy : P.Kp_body_p, kd = (i < 3) ? P.Kd_body_rpy : P.Kd_body_p;
-      c1_b[i] = LJ_b[i] - Ls_b[i] + kp * xt_b[i] + kd * xdt_b[i];
-      met_V += 0.5 * kp * xt_b[i] * xt_b[i];
-      met_Vdot += -kd * xdt_b[i] * xdt_b[i] + xdt_b[i] * c1_b[i];
-    }
+    double c1_b[6], c1_s[3];
     {
+      double Ls_b[6], Ls_s[3];
+      lam_mul(xdd_b, s1_s, Ls_b, Ls_s);
+      for (int i = 0; i < 6; i++) {
+        const double kp = (i < 3) ? P.Kp_body_rpy : P.Kp_body_p, kd = (i < 3) ? P.Kd_body_rpy : P.Kd_body_p;
+        c1_b[i] = LJ_b[i] - Ls_b[i] + kp * xt_b[i] + kd * xdt_b[i];
+        met_V += 0.5 * kp * xt_b[i] * xt_b[i];
+        met_Vdot += -kd * xdt_b[i] * xdt_b[i] + xdt_b[i] * c1_b[i];
+      }
       double lv = 0.0, lvd = 0.0;
       for (int i = 0; i < 3; i++) {
         c1_s[i] = LJ_s[i] - Ls_s[i] + P.Kp_foot * xt_s[i] + P.Kd_foot * xdt_s[i];
@@ -650,66 +682,106 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
       }
       for (int k = 0; k < 6; k++) vconst += Lx_b[k] * ab0[k];
     }
-    // body rows of sqrt(W) Lambda [B; Sel]
-    for (int i = 0; i < 6; i++) {
-      for (int j = 0; j < 3; j++) {
-        double s = 0.0;
-        for (int k = 0; k < 6; k++) s += Lbb[i][k] * B[k][j];
-        if (!ct) s += Mt_bl[3 * i + j];
-        blk[i][j] = sw_b * s;
+    WBC_STAMP(8);
+    // rows of sqrt(W) Lambda [B; Sel]: 6 body rows + 3 rows per swing leg.  The first two
+    // swing legs share one 12-row Householder append with the body rows (the trot case);
+    // further swing legs (nc < 2) go through a second 6-row append.
+    int sw_leg[4], ns = 0;
+    for (int lp = 0; lp < 4; lp++)
+      if (!((mask >> lp) & 1u)) sw_leg[ns++] = lp;
+    for (int lp = ns; lp < 4; lp++) sw_leg[lp] = -1;
+    auto swing_rows = [&](int lp, double (*b3)[3], double* r3) {
+      // lp is quad-uniform; lp < 0 -> zero rows
+      if (lp < 0) {
+        for (int i = 0; i < 3; i++) { b3[i][0] = b3[i][1] = b3[i][2] = 0.0; r3[i] = 0.0; }
+        return;
       }
-      double s = c1_b[i];
-      for (int k = 0; k < 6; k++) s += Lbb[i][k] * ab0[k];
-      brhs[i] = -sw_b * s;
-    }
-    quad_qr_append<Q, 6>(qo, l, Rc, rhsR, blk, brhs);
-    // swing rows: 3 per swing leg lp
-#pragma unroll
-    for (int lp = 0; lp < 4; lp++) {
-      if ((mask >> lp) & 1u) continue;  // quad-uniform
       double Mp[18], c1p[3];
 #pragma unroll
-      for (int i = 0; i < 18; i++) Mp[i] = qo.bcast_s(Mt_bl[i], lp);
+      for (int i = 0; i < 18; i++) Mp[i] = qo.bcast_d(st.get(ST_MTBL + i), lp);
 #pragma unroll
-      for (int i = 0; i < 3; i++) c1p[i] = qo.bcast_s(c1_s[i], lp);
-      double b3[3][3], r3[3];
+      for (int i = 0; i < 3; i++) c1p[i] = qo.bcast_d(c1_s[i], lp);
       for (int i = 0; i < 3; i++) {
         for (int j = 0; j < 3; j++) {
           double s = 0.0;
           for (int k = 0; k < 6; k++) s += Mp[3 * k + i] * B[k][j];
-          if (lp == l) s += Mt_ll[3 * i + j];
+          if (lp == l) s += st.get(ST_MTLL + 3 * i + j);
           b3[i][j] = sw_f * s;
         }
         double s = c1p[i];
         for (int k = 0; k < 6; k++) s += Mp[3 * k + i] * ab0[k];
         r3[i] = -sw_f * s;
       }
-      quad_qr_append<Q, 3>(qo, l, Rc, rhsR, b3, r3);
+    };
+    {
+      double blk[12][3], brhs[12];
+      for (int i = 0; i < 6; i++) {
+        for (int j = 0; j < 3; j++) {
+          double s = 0.0;
+          for (int k = 0; k < 6; k++) s += WBC_SH_GET(Lsh[6 * i + k]) * B[k][j];
+          if (!ct) s += st.get(ST_MTBL + 3 * i + j);
+          blk[i][j] = sw_b * s;
+        }
+        double s = c1_b[i];
+        for (int k = 0; k < 6; k++) s += WBC_SH_GET(Lsh[6 * i + k]) * ab0[k];
+        brhs[i] = -sw_b * s;
+      }
+      swing_rows(sw_leg[0], blk + 6, brhs + 6);
+      swing_rows(sw_leg[1], blk + 9, brhs + 9);
+      quad_qr_append<Q, 12>(qo, l, Rc, rhsR, blk, brhs);
+    }
+    if (ns > 2) {
+      double blk[6][3], brhs[6];
+      swing_rows(sw_leg[2], blk, brhs);
+      swing_rows(sw_leg[3], blk + 3, brhs + 3);
+      quad_qr_append<Q, 6>(qo, l, Rc, rhsR, blk, brhs);
     }
   }
-  // ---------------- level-2 rows eps (T z + t0)
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const int row = 6 * h + i;
-#pragma unroll
-      for (int j = 0; j < 3; j++) blk[i][j] = eps * Tc[row / 3][row % 3][j];
-      brhs[i] = -eps * t0[row];
-    }
-    quad_qr_append<Q, 6>(qo, l, Rc, rhsR, blk, brhs);
-  }
-  // ---------------- gather R, unconstrained minimiser, own rows of J = R^-1
-  double Rf[NZ][NZ];
-#pragma unroll
-  for (int lp = 0; lp < 4; lp++)
-#pragma unroll
-    for (int jj = 0; jj < 3; jj++)
-#pragma unroll
-      for (int k = 0; k < NZ; k++)
-        if (k <= 3 * lp + jj) Rf[k][3 * lp + jj] = qo.bcast_s(Rc[k][jj], lp);
-  double invd[NZ];
+  WBC_STAMP(9);
+  // ---------------- level-2 rows eps (T z + t0): own COLUMNS of the torque map, built here
+  //   T[3l'+i][3l+j] = (Y_l' B_l)[i][j] + delta_{l l'} D_l[i][j] ;  t0 replicated
   {
+    double blk[12][3], brhs[12];
+    double Y[18], Dl[9];  // Dl = own diagonal block D_l: -Jl' (contact) or Pm (swing)
+    for (int i = 0; i < 18; i++) Y[i] = st.get(ST_Y + i);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) Dl[3 * i + j] = ct ? -st.get(ST_JL + 3 * j + i) : st.get(ST_PM + 3 * i + j);
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) {
+      double Yp[18];
+#pragma unroll
+      for (int i = 0; i < 18; i++) Yp[i] = qo.bcast_s(Y[i], lp);
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        double t0r = qo.bcast_s(t0l[i], lp);
+#pragma unroll
+        for (int k = 0; k < 6; k++) t0r += Yp[6 * i + k] * ab0[k];
+        brhs[3 * lp + i] = -eps * t0r;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          double s = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; k++) s += Yp[6 * i + k] * B[k][j];
+          if (lp == l) s += Dl[3 * i + j];
+          blk[3 * lp + i][j] = eps * s;
+        }
+      }
+    }
+    quad_qr_append<Q, 12>(qo, l, Rc, rhsR, blk, brhs);
+  }
+  WBC_STAMP(10);
+  // ---------------- gather R, unconstrained minimiser, own rows of J = R^-1
+  double zl[3], Jr[3][NZ];
+  {
+    double Rf[NZ][NZ];
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++)
+#pragma unroll
+      for (int jj = 0; jj < 3; jj++)
+#pragma unroll
+        for (int k = 0; k < NZ; k++)
+          if (k <= 3 * lp + jj) Rf[k][3 * lp + jj] = qo.bcast_s(Rc[k][jj], lp);
+    double invd[NZ];
     double rmax = 0.0, rmin = 0.0;
 #pragma unroll
     for (int i = 0; i < NZ; i++) {
@@ -719,39 +791,38 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
       invd[i] = 1.0 / Rf[i][i];
     }
     if (!(rmin > 1e-13 * rmax)) status = ST_SINGULAR;
-  }
-  if (status == ST_SINGULAR) {
-    for (int k = 0; k < 3; k++) out_tau(3 * l + k, 0.0);
-    out_met(0, 0.0); out_met(1, met_err); out_met(2, 0.0); out_met(3, 0.0);
-    *iters_out = 0;
-    return status;
-  }
-  double z[NZ];
+    if (status == ST_SINGULAR) {
+      for (int k = 0; k < 3; k++) out_tau(m.act_inv[3 * l + k], 0.0);
+      out_met(0, 0.0); out_met(1, met_err); out_met(2, 0.0); out_met(3, 0.0);
+      *iters_out = 0;
+      return status;
+    }
+    double z[NZ];
 #pragma unroll
-  for (int k = NZ - 1; k >= 0; k--) {
-    double s = rhsR[k];
+    for (int k = NZ - 1; k >= 0; k--) {
+      double s = rhsR[k];
 #pragma unroll
-    for (int j = k + 1; j < NZ; j++) s -= Rf[k][j] * z[j];
-    z[k] = s * invd[k];
-  }
-  double zl[3];
+      for (int j = k + 1; j < NZ; j++) s -= Rf[k][j] * z[j];
+      z[k] = s * invd[k];
+    }
 #pragma unroll
-  for (int k = 0; k < NZ; k++)
+    for (int k = 0; k < NZ; k++)
 #pragma unroll
-    for (int jj = 0; jj < 3; jj++)
-      if (k == 3 * l + jj) zl[jj] = z[k];
-  double Jr[3][NZ];
+      for (int jj = 0; jj < 3; jj++)
+        if (k == 3 * l + jj) zl[jj] = z[k];
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
-    const int row = 3 * l + i;
+    for (int i = 0; i < 3; i++) {
+      const int row = 3 * l + i;
 #pragma unroll
-    for (int c = 0; c < NZ; c++) {
-      double s = (c == row) ? 1.0 : 0.0;
+      for (int c = 0; c < NZ; c++) {
+        double s = (c == row) ? 1.0 : 0.0;
 #pragma unroll
-      for (int k = 0; k < c; k++) s -= Jr[i][k] * Rf[k][c];
-      Jr[i][c] = s * invd[c];
+        for (int k = 0; k < c; k++) s -= Jr[i][k] * Rf[k][c];
+        Jr[i][c] = s * invd[c];
+      }
     }
   }
+  WBC_STAMP(11);
   // ---------------- friction rows
   int iters = 0;
   {
@@ -760,23 +831,22 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
     if (st != ST_OK) status = st;
   }
   *iters_out = iters;
-  // ---------------- outputs
-  double tauc[NZ];
-#pragma unroll
-  for (int lp = 0; lp < 4; lp++)
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-      tauc[3 * lp + i] = t0[3 * lp + i] + qo.sum(Tc[lp][i][0] * zl[0] + Tc[lp][i][1] * zl[1] + Tc[lp][i][2] * zl[2]);
-  for (int k = 0; k < 3; k++) {
-    const int idx = m.act_perm[3 * l + k];
-    double v = 0.0;
-#pragma unroll
-    for (int c = 0; c < NZ; c++) v = (c == idx) ? tauc[c] : v;
-    out_tau(3 * l + k, (status == ST_SINGULAR) ? 0.0 : v);
+  WBC_STAMP(12);
+  // ---------------- outputs: a_b = ab0 + sum_l B_l z_l ;  tau_l = Y_l a_b + D_l z_l + t0l
+  {
+    double ab[6];
+    for (int i = 0; i < 6; i++) ab[i] = ab0[i] + qo.sum(B[i][0] * zl[0] + B[i][1] * zl[1] + B[i][2] * zl[2]);
+    for (int i = 0; i < 3; i++) {
+      double s = t0l[i];
+      for (int k = 0; k < 6; k++) s += st.get(ST_Y + 6 * i + k) * ab[k];
+      for (int j = 0; j < 3; j++) s += (ct ? -st.get(ST_JL + 3 * j + i) : st.get(ST_PM + 3 * i + j)) * zl[j];
+      out_tau(m.act_inv[3 * l + i], (status == ST_SINGULAR) ? 0.0 : s);
+    }
   }
   double res = 0.0;
   if (ct) res = fmax(fabs(zl[0]) - mu * zl[2], fabs(zl[1]) - mu * zl[2]);
   res = fmax(0.0, qo.max(res));
+  WBC_STAMP(13);
   if (KIND == KIND_MPTC) {
     met_Vdot += vconst + qo.sum(vrow[0] * zl[0] + vrow[1] * zl[1] + vrow[2] * zl[2]);
     out_met(0, met_V); out_met(1, met_err); out_met(2, 0.0); out_met(3, met_Vdot);

@@ -31,7 +31,41 @@
 #define WBC_HDN
 #endif
 
+// Phase fence: on the device it (a) stops the instruction scheduler from interleaving two phases
+// (which inflates register live ranges in this VGPR-bound kernel) and (b) makes LDS-resident
+// data be re-read instead of being kept in registers.  No-op on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WBC_PHASE_FENCE() do { } while (0)
+#else
+#define WBC_PHASE_FENCE() do { } while (0)
+#endif
+
+// Diagnostic builds only (-DWBC_STAMPS): shader-clock stamps at phase boundaries, written by lane 0
+// of each block to a side buffer that nothing else reads.  Expands to nothing in the product build.
+#if defined(WBC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define WBC_STAMP(i)                                                                                  \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    unsigned long long t_;                                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+    if (threadIdx.x == 0) g_wbc_stamps[(size_t)blockIdx.x * 16 + (i)] = t_;                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+#else
+#define WBC_STAMP(i) do { } while (0)
+#endif
+
 namespace wbc {
+
+// one range reduction for both (the f64 sin/cos are long software routines on the GPU)
+WBC_HD void wbc_sincos(double x, double& s, double& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincos(x, &s, &c);
+#else
+  s = sin(x); c = cos(x);
+#endif
+}
+template <class T> WBC_HD void wbc_sincos(const T& x, T& s, T& c) { s = sin(x); c = cos(x); }
 
 enum { KIND_ID = 0, KIND_MPTC = 1 };
 enum { ST_OK = 0, ST_ITER = 1, ST_SINGULAR = 2 };
@@ -51,6 +85,7 @@ struct ModelC {
   double gravity;
   int q_perm[12];    // canonical joint j is read from input row 7 + q_perm[j] / 6 + q_perm[j]
   int act_perm[12];  // output row k (actuator k) = canonical joint act_perm[k]
+  int act_inv[12];   // canonical joint j is written to output row act_inv[j]
 };
 struct ParamsC {
   double Kp_body_p, Kd_body_p, Kp_body_rpy, Kd_body_rpy, Kp_foot, Kd_foot;
@@ -107,12 +142,23 @@ template <class T> WBC_HD void shift_add(const T& m, const T* h, const T* I, con
 }
 
 // ---------------------------------------------------------------- per-leg data
-template <class T> struct LegKin {  // world-aligned, positions relative to the base origin
-  T r[3][3];    // link origins
-  T ax[3][3];   // joint axes
-  T mcw[3][3];  // first moments m*c in world axes
-  T Iw[3][6];   // inertia about the link origin in world axes
-  T rf[3];      // foot position
+// Per-leg kinematics cache, world-aligned, positions relative to the base origin.  Accessed only
+// through the accessors below so that the storage can be registers (LegKin) or a lane-strided LDS
+// arena (LegKinLds in wbc_kernels.hip): r = link origins, ax = joint axes, mcw = first moments
+// m*c, Iw = inertia about the link origin (xx yy zz xy xz yz), rf = foot position.
+enum { KIN_R = 0, KIN_AX = 9, KIN_MCW = 18, KIN_IW = 27, KIN_RF = 45, KIN_N = 48 };
+template <class T> struct LegKin {
+  T d[KIN_N];
+  WBC_HD T& r(int k, int i) { return d[KIN_R + 3 * k + i]; }
+  WBC_HD T& ax(int k, int i) { return d[KIN_AX + 3 * k + i]; }
+  WBC_HD T& mcw(int k, int i) { return d[KIN_MCW + 3 * k + i]; }
+  WBC_HD T& Iw(int k, int i) { return d[KIN_IW + 6 * k + i]; }
+  WBC_HD T& rf(int i) { return d[KIN_RF + i]; }
+  WBC_HD const T& r(int k, int i) const { return d[KIN_R + 3 * k + i]; }
+  WBC_HD const T& ax(int k, int i) const { return d[KIN_AX + 3 * k + i]; }
+  WBC_HD const T& mcw(int k, int i) const { return d[KIN_MCW + 3 * k + i]; }
+  WBC_HD const T& Iw(int k, int i) const { return d[KIN_IW + 6 * k + i]; }
+  WBC_HD const T& rf(int i) const { return d[KIN_RF + i]; }
 };
 template <class T> struct LegDyn {
   T Jl[9];    // d(foot velocity)/d(own joint rates), row-major 3x3
@@ -127,8 +173,8 @@ template <class T> struct LegDyn {
 };
 
 // Forward kinematics of one leg from cached sines/cosines.
-template <class T>
-WBC_HD void leg_fk(const ModelC& m, int l, const T* R0, const T* sn, const T* cs, LegKin<T>& K) {
+template <class T, class KinT>
+WBC_HD void leg_fk(const ModelC& m, int l, const T* R0, const T* sn, const T* cs, KinT& K) {
   T R[9];
   for (int i = 0; i < 9; i++) R[i] = R0[i];
   T p[3] = {T(0.0), T(0.0), T(0.0)};
@@ -136,100 +182,102 @@ WBC_HD void leg_fk(const ModelC& m, int l, const T* R0, const T* sn, const T* cs
     const LinkC& L = m.link[l][k];
     T off[3] = {T(L.off[0]), T(L.off[1]), T(L.off[2])}, t[3];
     rotv(R, off, t);
-    for (int i = 0; i < 3; i++) { p[i] = p[i] + t[i]; K.r[k][i] = p[i]; }
+    for (int i = 0; i < 3; i++) { p[i] = p[i] + t[i]; K.r(k, i) = p[i]; }
     int a = L.axis, b = (a + 1) % 3, c = (a + 2) % 3;
     T s = T(L.sgn) * sn[k], co = cs[k];
     for (int i = 0; i < 3; i++) {
-      K.ax[k][i] = T(L.sgn) * R[3 * i + a];
+      K.ax(k, i) = T(L.sgn) * R[3 * i + a];
       // R <- R * Rot(axis a, angle): columns b, c mix
       T cb = R[3 * i + b], cc = R[3 * i + c];
       R[3 * i + b] = cb * co + cc * s;
       R[3 * i + c] = cc * co - cb * s;
     }
-    T mc[3] = {T(L.mc[0]), T(L.mc[1]), T(L.mc[2])};
-    rotv(R, mc, K.mcw[k]);
-    rot_inertia(R, L.I, K.Iw[k]);
+    T mc[3] = {T(L.mc[0]), T(L.mc[1]), T(L.mc[2])}, mcw[3], Iw[6];
+    rotv(R, mc, mcw);
+    rot_inertia(R, L.I, Iw);
+    for (int i = 0; i < 3; i++) K.mcw(k, i) = mcw[i];
+    for (int i = 0; i < 6; i++) K.Iw(k, i) = Iw[i];
   }
   T fo[3] = {T(m.foot_off[l][0]), T(m.foot_off[l][1]), T(m.foot_off[l][2])}, t[3];
   rotv(R, fo, t);
-  for (int i = 0; i < 3; i++) K.rf[i] = p[i] + t[i];
+  for (int i = 0; i < 3; i++) K.rf(i) = p[i] + t[i];
 }
 
 // Newton-Euler bias pass for one leg (vd = 0): joint torques hl and the leg's reaction wrench
 // (Nb about the base origin, Fb).  w0 = base angular velocity, qd = own joint rates, gz = gravity.
 // Optionally also returns the foot bias acceleration / velocities / Jd columns.
-template <class T, bool KINEXTRA>
-WBC_HD void leg_rnea(const ModelC& m, int l, const LegKin<T>& K, const T* w0, const T* qd, T gz, T* hl, T* Nb,
+template <class T, bool KINEXTRA, class KinT>
+WBC_HD void leg_rnea(const ModelC& m, int l, const KinT& K, const T* w0, const T* qd, T gz, T* hl, T* Nb,
                      T* Fb, LegDyn<T>* D) {
   T w[3] = {w0[0], w0[1], w0[2]};
   T al[3] = {T(0.0), T(0.0), T(0.0)};
   T a[3] = {T(0.0), T(0.0), T(0.0)};   // origin acceleration minus base-origin acceleration (=0)
   T vo[3] = {T(0.0), T(0.0), T(0.0)};  // origin velocity relative to the base origin velocity
   T F[3][3], N[3][3];
-  const T* rp = nullptr;
+  T rk[3][3], axk[3][3];
+  T rfv[3] = {K.rf(0), K.rf(1), K.rf(2)};
   for (int k = 0; k < 3; k++) {
+    for (int i = 0; i < 3; i++) { rk[k][i] = K.r(k, i); axk[k][i] = K.ax(k, i); }
     T r[3];
-    for (int i = 0; i < 3; i++) r[i] = K.r[k][i] - (k ? rp[i] : T(0.0));
+    for (int i = 0; i < 3; i++) r[i] = rk[k][i] - (k ? rk[k - 1][i] : T(0.0));
     T wxr[3], t[3], alxr[3], wxa[3];
     cross(w, r, wxr);
     cross(w, wxr, t);
     cross(al, r, alxr);
-    cross(w, K.ax[k], wxa);
+    cross(w, axk[k], wxa);
     for (int i = 0; i < 3; i++) {
       a[i] = a[i] + alxr[i] + t[i];
       vo[i] = vo[i] + wxr[i];
       al[i] = al[i] + wxa[i] * qd[k];
     }
     if (KINEXTRA) {
-      // Jd column k = (w_parent x a_k) x (rf - r_k) + a_k x (vf - v_k); vf filled below
-      T d[3] = {K.rf[0] - K.r[k][0], K.rf[1] - K.r[k][1], K.rf[2] - K.r[k][2]}, c1[3];
+      // Jd column k = (w_parent x a_k) x (rf - r_k) + a_k x (vf - v_k); the a_k x vf part is added below
+      T d[3] = {rfv[0] - rk[k][0], rfv[1] - rk[k][1], rfv[2] - rk[k][2]}, c1[3], c2[3];
       cross(wxa, d, c1);
-      for (int i = 0; i < 3; i++) { D->Jd[3 * i + k] = c1[i]; }
-      // stash -a_k x v_k part now (v_k = vo)
-      T c2[3];
-      cross(K.ax[k], vo, c2);
-      for (int i = 0; i < 3; i++) D->Jd[3 * i + k] = D->Jd[3 * i + k] - c2[i];
+      cross(axk[k], vo, c2);
+      for (int i = 0; i < 3; i++) D->Jd[3 * i + k] = c1[i] - c2[i];
     }
-    for (int i = 0; i < 3; i++) w[i] = w[i] + K.ax[k][i] * qd[k];
+    for (int i = 0; i < 3; i++) w[i] = w[i] + axk[k][i] * qd[k];
     // body wrench about the link origin
+    T mcw[3] = {K.mcw(k, 0), K.mcw(k, 1), K.mcw(k, 2)};
+    T Iw[6] = {K.Iw(k, 0), K.Iw(k, 1), K.Iw(k, 2), K.Iw(k, 3), K.Iw(k, 4), K.Iw(k, 5)};
     T ag[3] = {a[0], a[1], a[2] + gz};
     T t1[3], t2[3], t3[3], Iw_w[3], Ial[3];
-    cross(al, K.mcw[k], t1);
-    cross(w, K.mcw[k], t2);
+    cross(al, mcw, t1);
+    cross(w, mcw, t2);
     cross(w, t2, t2);
-    symv(K.Iw[k], w, Iw_w);
-    symv(K.Iw[k], al, Ial);
+    symv(Iw, w, Iw_w);
+    symv(Iw, al, Ial);
     cross(w, Iw_w, t3);
     T mk = T(m.link[l][k].mass), t4[3];
-    cross(K.mcw[k], ag, t4);
+    cross(mcw, ag, t4);
     for (int i = 0; i < 3; i++) {
       F[k][i] = mk * ag[i] + t1[i] + t2[i];
       N[k][i] = Ial[i] + t3[i] + t4[i];
     }
-    rp = K.r[k];
   }
   if (KINEXTRA) {
     // foot: d = rf - r_shank
-    T d[3] = {K.rf[0] - K.r[2][0], K.rf[1] - K.r[2][1], K.rf[2] - K.r[2][2]};
+    T d[3] = {rfv[0] - rk[2][0], rfv[1] - rk[2][1], rfv[2] - rk[2][2]};
     T wxd[3], t[3], alxd[3];
     cross(w, d, wxd);
     cross(w, wxd, t);
     cross(al, d, alxd);
     for (int i = 0; i < 3; i++) {
-      D->Jdv[i] = a[i] + alxd[i] + t[i];   // + base terms added by the caller (w0 x (w0 x r) is inside a)
+      D->Jdv[i] = a[i] + alxd[i] + t[i];
       D->rd[i] = vo[i] + wxd[i];
     }
     for (int k = 0; k < 3; k++) {
       T c2[3];
-      cross(K.ax[k], D->rd, c2);
+      cross(axk[k], D->rd, c2);
       for (int i = 0; i < 3; i++) D->Jd[3 * i + k] = D->Jd[3 * i + k] + c2[i];
     }
   }
   // inward pass
   for (int k = 2; k >= 0; k--) {
-    hl[k] = dot(K.ax[k], N[k]);
+    hl[k] = dot(axk[k], N[k]);
     T r[3], rxF[3];
-    for (int i = 0; i < 3; i++) r[i] = K.r[k][i] - (k ? K.r[k - 1][i] : T(0.0));
+    for (int i = 0; i < 3; i++) r[i] = rk[k][i] - (k ? rk[k - 1][i] : T(0.0));
     cross(r, F[k], rxF);
     if (k > 0)
       for (int i = 0; i < 3; i++) { F[k - 1][i] = F[k - 1][i] + F[k][i]; N[k - 1][i] = N[k - 1][i] + N[k][i] + rxF[i]; }
@@ -239,47 +287,52 @@ WBC_HD void leg_rnea(const ModelC& m, int l, const LegKin<T>& K, const T* w0, co
 }
 
 // Composite-rigid-body pass for one leg: Mbl, Mll and the leg's composite inertia at the base origin.
-template <class T>
-WBC_HD void leg_crba(const ModelC& m, int l, const LegKin<T>& K, LegDyn<T>& D, T& Mc, T* Hc, T* Ic) {
+template <class T, class KinT>
+WBC_HD void leg_crba(const ModelC& m, int l, const KinT& K, LegDyn<T>& D, T& Mc, T* Hc, T* Ic) {
   T cm = T(0.0), ch[3] = {T(0.0), T(0.0), T(0.0)}, cI[6] = {T(0.0), T(0.0), T(0.0), T(0.0), T(0.0), T(0.0)};
+  T rk[3][3], axk[3][3];
+  for (int k = 0; k < 3; k++)
+    for (int i = 0; i < 3; i++) { rk[k][i] = K.r(k, i); axk[k][i] = K.ax(k, i); }
   for (int k = 2; k >= 0; k--) {
     // composite of links k..2 about origin k
     T zero[3] = {T(0.0), T(0.0), T(0.0)};
     T nm = T(0.0), nh[3] = {T(0.0), T(0.0), T(0.0)}, nI[6] = {T(0.0), T(0.0), T(0.0), T(0.0), T(0.0), T(0.0)};
     if (k < 2) {
-      T r[3] = {K.r[k + 1][0] - K.r[k][0], K.r[k + 1][1] - K.r[k][1], K.r[k + 1][2] - K.r[k][2]};
+      T r[3] = {rk[k + 1][0] - rk[k][0], rk[k + 1][1] - rk[k][1], rk[k + 1][2] - rk[k][2]};
       shift_add(cm, ch, cI, r, nm, nh, nI);
     }
     T mk = T(m.link[l][k].mass);
-    shift_add(mk, K.mcw[k], K.Iw[k], zero, nm, nh, nI);
+    T mcw[3] = {K.mcw(k, 0), K.mcw(k, 1), K.mcw(k, 2)};
+    T Iw[6] = {K.Iw(k, 0), K.Iw(k, 1), K.Iw(k, 2), K.Iw(k, 3), K.Iw(k, 4), K.Iw(k, 5)};
+    shift_add(mk, mcw, Iw, zero, nm, nh, nI);
     cm = nm;
     for (int i = 0; i < 3; i++) ch[i] = nh[i];
     for (int i = 0; i < 6; i++) cI[i] = nI[i];
     // unit joint acceleration of joint k: n = I a, f = a x h  (about origin k)
     T n[3], f[3];
-    symv(cI, K.ax[k], n);
-    cross(K.ax[k], ch, f);
+    symv(cI, axk[k], n);
+    cross(axk[k], ch, f);
     // diagonal and ancestors within the leg
     T nk[3] = {n[0], n[1], n[2]};
     for (int j = k; j >= 0; j--) {
       if (j < k) {
-        T r[3] = {K.r[j + 1][0] - K.r[j][0], K.r[j + 1][1] - K.r[j][1], K.r[j + 1][2] - K.r[j][2]}, rxf[3];
+        T r[3] = {rk[j + 1][0] - rk[j][0], rk[j + 1][1] - rk[j][1], rk[j + 1][2] - rk[j][2]}, rxf[3];
         cross(r, f, rxf);
         for (int i = 0; i < 3; i++) nk[i] = nk[i] + rxf[i];
       }
-      T v = dot(K.ax[j], nk);
+      T v = dot(axk[j], nk);
       // symmetric 3x3 index of (j,k), j<=k
       int idx = (j == k) ? j : (j == 0 ? (k == 1 ? 3 : 4) : 5);
       D.Mll[idx] = v;
     }
     T rxf[3];
-    cross(K.r[0], f, rxf);
+    cross(rk[0], f, rxf);
     for (int i = 0; i < 3; i++) {
       D.Mbl[(i)*3 + k] = nk[i] + rxf[i];
       D.Mbl[(3 + i) * 3 + k] = f[i];
     }
   }
-  shift_add(cm, ch, cI, K.r[0], Mc, Hc, Ic);
+  shift_add(cm, ch, cI, rk[0], Mc, Hc, Ic);
 }
 
 // 3x3 inverse; returns |det| relative measure
@@ -560,7 +613,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     for (int k = 0; k < 3; k++) {
       int row = m.q_perm[3 * l + k];
       T th = in(7 + row);
-      sn[k] = sin(th); cs[k] = cos(th);
+      wbc_sincos(th, sn[k], cs[k]);
       qd[l][k] = in(25 + row);
     }
     leg_fk(m, l, R0, sn, cs, K[l]);
@@ -570,8 +623,9 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     leg_crba(m, l, K[l], D[l], Mc, Hc, Ic);
     // foot Jacobian block wrt own joints
     for (int k = 0; k < 3; k++) {
-      T d[3] = {K[l].rf[0] - K[l].r[k][0], K[l].rf[1] - K[l].r[k][1], K[l].rf[2] - K[l].r[k][2]}, c[3];
-      cross(K[l].ax[k], d, c);
+      T d[3] = {K[l].rf(0) - K[l].r(k, 0), K[l].rf(1) - K[l].r(k, 1), K[l].rf(2) - K[l].r(k, 2)}, c[3];
+      T axv[3] = {K[l].ax(k, 0), K[l].ax(k, 1), K[l].ax(k, 2)};
+      cross(axv, d, c);
       for (int i = 0; i < 3; i++) D[l].Jl[3 * i + k] = c[i];
     }
     T det = inv3(D[l].Jl, D[l].Ji);
@@ -621,7 +675,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
   T kvec[6];
   for (int i = 0; i < 6; i++) kvec[i] = hb[i];
   for (int l = 0; l < 4; l++) {
-    const T* r = K[l].rf;
+    const T* r = &K[l].rf(0);
     for (int i = 0; i < 6; i++)
       for (int j = 0; j < 3; j++)
         X[l][3 * i + j] = D[l].Mbl[3 * i] * D[l].Ji[j] + D[l].Mbl[3 * i + 1] * D[l].Ji[3 + j] + D[l].Mbl[3 * i + 2] * D[l].Ji[6 + j];
@@ -664,7 +718,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
   lu6_solve(Gb, piv, ab0);
   for (int l = 0; l < 4; l++) {
     bool ct = (mask >> l) & 1;
-    const T* r = K[l].rf;
+    const T* r = &K[l].rf(0);
     for (int j = 0; j < 3; j++) {
       T col[6];
       if (ct) {  // W_l e_j = [r x e_j; e_j]
@@ -723,7 +777,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       bool ct = (mask >> l) & 1;
       for (int i = 0; i < 3; i++) {
         if (ct) { Rf[3 * l + i][3 * l + i] = eps; continue; }
-        T pf = p0[i] + K[l].rf[i];
+        T pf = p0[i] + K[l].rf(i);
         T tp = in(37 + 18 + 9 * l + i), tpd = in(37 + 21 + 9 * l + i), tpdd = in(37 + 24 + 9 * l + i);
         T des = tpdd - T(P.Kp_foot) * (pf - tp) - T(P.Kd_foot) * (D[l].pd[i] - tpd);
         Rf[3 * l + i][3 * l + i] = sw_f;
@@ -742,7 +796,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     T Mt_bb[6][6], Mt_bl[4][18], Mt_ll[4][9], Mli[4][9];
     for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Mt_bb[i][j] = Gs[i][j];
     for (int l = 0; l < 4; l++) {
-      const T* r = K[l].rf;
+      const T* r = &K[l].rf(0);
       // A_l = Ji Jfb (3x6) = [ -Ji [r]x , Ji ]
       T A[18];
       for (int i = 0; i < 3; i++) {
@@ -795,7 +849,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     for (int l = 0; l < 4; l++)
       for (int i = 0; i < 3; i++) {
         bool ct = (mask >> l) & 1;
-        T pf = p0[i] + K[l].rf[i];
+        T pf = p0[i] + K[l].rf(i);
         xt_s[l][i] = ct ? T(0.0) : pf - in(37 + 18 + 9 * l + i);
         xdt_s[l][i] = ct ? T(0.0) : D[l].pd[i] - in(37 + 21 + 9 * l + i);
         xdd_s[l][i] = ct ? T(0.0) : in(37 + 24 + 9 * l + i);
@@ -805,7 +859,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     //   swing: xdt_s ; contact: y_c = -Jl Mll^-1 Y_l xdt_b   ->  xi_l = Ji (y_l - Jfb xdt_b)
     T xi_l[4][3];
     for (int l = 0; l < 4; l++) {
-      const T* r = K[l].rf;
+      const T* r = &K[l].rf(0);
       T jfb[3], t[3];
       cross(xdt_b, r, t);  // omega x r
       for (int i = 0; i < 3; i++) jfb[i] = xdt_b[3 + i] + t[i];
@@ -848,7 +902,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     T LJMC_b[6], LJMC_s[4][3];
     for (int i = 0; i < 6; i++) LJMC_b[i] = Cxi_b[i];
     for (int l = 0; l < 4; l++) {
-      const T* r = K[l].rf;
+      const T* r = &K[l].rf(0);
       T gl[3];  // Ji' w_l
       for (int i = 0; i < 3; i++) gl[i] = D[l].Ji[i] * Cxi_l[l][0] + D[l].Ji[3 + i] * Cxi_l[l][1] + D[l].Ji[6 + i] * Cxi_l[l][2];
       // A_l' w_l = Jfb' gl = [r x gl ; gl]

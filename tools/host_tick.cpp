@@ -57,8 +57,7 @@ int host_tick_batch(int kind, const double* flat215, const double* params12, con
                     double* tau, double* met, int* status, int* iters) {
   wbc::ModelC m;
   if (wbc::model_from_flat(flat215, &m)) return -1;
-  if (q_perm) for (int i = 0; i < 12; i++) m.q_perm[i] = q_perm[i];
-  if (act_perm) for (int i = 0; i < 12; i++) m.act_perm[i] = act_perm[i];
+  wbc::model_set_perms(&m, q_perm, act_perm);
   wbc::ParamsC P;
   wbc::params_default(kind, &P);
   if (params12) memcpy(&P, params12, sizeof(double) * 12);
@@ -126,6 +125,7 @@ struct QuadHost {
     double r = c->slot[src]; c->bar.arrive_and_wait();
     return r;
   }
+  double bcast_d(double x, int src) { return bcast_s(x, src); }
   double sum(double x) {  // same association as the DPP butterfly: (x_l + x_{l^1}) + (x_{l^2} + x_{l^3})
     c->slot[l] = x; c->bar.arrive_and_wait();
     double a = c->slot[l] + c->slot[l ^ 1], b = c->slot[l ^ 2] + c->slot[l ^ 3];
@@ -162,8 +162,7 @@ extern "C" int host_quad_batch(int kind, const double* flat215, const double* pa
                                const double* mass_scale, double* tau, double* met, int* status, int* iters) {
   wbc::ModelC m;
   if (wbc::model_from_flat(flat215, &m)) return -1;
-  if (q_perm) for (int i = 0; i < 12; i++) m.q_perm[i] = q_perm[i];
-  if (act_perm) for (int i = 0; i < 12; i++) m.act_perm[i] = act_perm[i];
+  wbc::model_set_perms(&m, q_perm, act_perm);
   wbc::ParamsC P;
   wbc::params_default(kind, &P);
   if (params12) memcpy(&P, params12, sizeof(double) * 12);
@@ -182,8 +181,10 @@ extern "C" int host_quad_batch(int kind, const double* flat215, const double* pa
       auto om = [&](int k, double x) { if (l == 0 && met) met[(size_t)k * stride + i] = x; };
       int it = 0, st;
       double mui = mu ? mu[i] : P.mu, msi = mass_scale ? mass_scale[i] : 1.0;
-      if (kind == wbc::KIND_ID) st = wbc::quad_tick<QuadHost, wbc::KIND_ID>(m, P, qo, in, mask[i], mui, msi, sh, ot, om, &it);
-      else st = wbc::quad_tick<QuadHost, wbc::KIND_MPTC>(m, P, qo, in, mask[i], mui, msi, sh, ot, om, &it);
+      wbc::LegKin<double> K;
+      wbc::StageReg<double> sg;
+      if (kind == wbc::KIND_ID) st = wbc::quad_tick<QuadHost, wbc::KIND_ID>(m, P, qo, in, mask[i], mui, msi, K, sg, sh, ot, om, &it);
+      else st = wbc::quad_tick<QuadHost, wbc::KIND_MPTC>(m, P, qo, in, mask[i], mui, msi, K, sg, sh, ot, om, &it);
       if (l == 0) { if (status) status[i] = st; if (iters) iters[i] = it; }
     }
   };
