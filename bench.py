@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 # Counted with the operation-counting scalar (tools/host_tick.cpp) on the full config; frozen in
 # BASELINE.md section 4.  add + mul + div + sqrt each count 1 (an FMA is 2); trig/compare are not counted.
-FLOPS_PER_TICK = {("mptc", 3): 37623.0, ("mptc", 5): 37775.0, ("id", 2): 35667.0, ("mptc", 4): 36075.0}
+FLOPS_PER_TICK = {("mptc", 3): 37629.0, ("mptc", 5): 37703.0, ("id", 2): 35667.0, ("mptc", 4): 36085.0}
 BYTES_PER_TICK = {False: 864.0, True: 880.0}     # SURVEY.md section 8(d); True = with mu and mass scale
 PEAK_FP64_VALU_TFLOPS = 78.6                      # MI355X vector FP64 (spec); FP64 MFMA peak is the same figure
 PEAK_HBM_GBS = 8000.0
@@ -124,10 +124,21 @@ def main():
     if rank == 0:
         status = out[2].cpu().numpy()
         key = (shard["kind"], cfg)
-        flops = FLOPS_PER_TICK.get(key, 37623.0)
+        flops = FLOPS_PER_TICK.get(key, 37629.0)
         bpt = BYTES_PER_TICK[mu is not None]
         sec = ms_per_launch * 1e-3
         achieved = flops * n / sec / 1e12
+        # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+        # (separate runs; committed under profiles/): null when no measurement matches this build
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+                tr = json.load(f)
+            ent = tr.get("%s_cfg%d_n%d_%s" % (shard["kind"], cfg, n, "lane" if a.variant == "lane" else "quad"))
+            if ent:
+                traffic = ent["bytes_per_launch"]
+        except (OSError, ValueError):
+            pass
         line = {
             "metric": "whole-body-QP control ticks/s at N=4096 Mini Cheetah",
             "value": n_total * a.steps / dt, "unit": "ticks/s",
@@ -140,7 +151,7 @@ def main():
                 "instances_per_gpu": n, "seed": shard["seed"],
                 "domain_randomised": mu is not None, "parallelism": "batch-shard x%d" % world},
             "roofline": {"bound": "valu-f64", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                          "kernel": "%s<%s>" % ("wbc_tick_kernel" if a.variant == "lane" else "wbc_quad_kernel", shard["kind"].upper()),
                          "kernel_ms": ms_per_launch, "flops_per_tick": flops,
                          "hbm": {"achieved_GBs": bpt * n / sec / 1e9, "peak_GBs": PEAK_HBM_GBS,

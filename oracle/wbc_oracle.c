@@ -78,7 +78,7 @@ static void mtv(int m, int n, const double* A, const double* x, double* y) { /* 
 /* In-place inverse by Gauss-Jordan with partial pivoting (np.linalg.inv restatement:
  * mptc_controller.py:237-238).  Returns 0 on success. */
 static int mat_inv(int n, double* A) {
-  double* W = (double*)malloc(sizeof(double) * n * 2 * n);
+  double W[18 * 36]; /* n <= 18 on this path; no heap traffic in the hot loop */
   for (int i = 0; i < n; i++)
     for (int j = 0; j < n; j++) {
       W[i * 2 * n + j] = A[i * n + j];
@@ -88,7 +88,7 @@ static int mat_inv(int n, double* A) {
     int piv = c;
     for (int r = c + 1; r < n; r++)
       if (fabs(W[r * 2 * n + c]) > fabs(W[piv * 2 * n + c])) piv = r;
-    if (fabs(W[piv * 2 * n + c]) < 1e-300) { free(W); return 1; }
+    if (fabs(W[piv * 2 * n + c]) < 1e-300) return 1;
     if (piv != c)
       for (int j = 0; j < 2 * n; j++) { double t = W[c * 2 * n + j]; W[c * 2 * n + j] = W[piv * 2 * n + j]; W[piv * 2 * n + j] = t; }
     double d = 1.0 / W[c * 2 * n + c];
@@ -102,7 +102,6 @@ static int mat_inv(int n, double* A) {
   }
   for (int i = 0; i < n; i++)
     for (int j = 0; j < n; j++) A[i * n + j] = W[i * 2 * n + n + j];
-  free(W);
   return 0;
 }
 
@@ -385,7 +384,7 @@ static void rpy_Einv(const double* rpy, double* Ei) {
 /* Householder QR of A (m x n, m >= n), in place: R in the upper triangle; Q (m x m) explicit. */
 static void householder_qr(int m, int n, double* A, double* Q) {
   for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Q[i * m + j] = (i == j);
-  double* w = (double*)malloc(sizeof(double) * m);
+  double w[64]; /* m <= 60 here */
   for (int k = 0; k < n && k < m - 1; k++) {
     double nrm = 0;
     for (int i = k; i < m; i++) nrm += A[i * n + k] * A[i * n + k];
@@ -411,7 +410,6 @@ static void householder_qr(int m, int n, double* A, double* Q) {
       for (int l = k; l < m; l++) Q[i * m + l] -= s * w[l];
     }
   }
-  free(w);
 }
 
 /* Goldfarb-Idnani dual active set.
@@ -529,9 +527,10 @@ int orc_qp_solve(int n, int mls, const double* Als, const double* bls, double ep
                  const double* bin, double* x, int* iters, double* primal_res) {
   int nz = n - me, status = 0;
   *iters = 0;
-  double* At = (double*)malloc(sizeof(double) * n * (me > 0 ? me : 1));
-  double* Q = (double*)malloc(sizeof(double) * n * n);
-  double* xp = (double*)calloc(n, sizeof(double));
+  /* fixed workspaces (n <= 42, me <= 30, reduced rows <= 60): the hot loop never touches the heap */
+  double At[42 * 30], Q[42 * 42], xp[42];
+  if (n > 42 || me > 30) return 2;
+  memset(xp, 0, sizeof xp);
   /* 1. null-space basis of the equalities: Aeq' = Q [R1; 0] */
   for (int i = 0; i < me; i++) for (int j = 0; j < n; j++) At[j * me + i] = Aeq[i * n + j];
   if (me > 0) householder_qr(n, me, At, Q);
@@ -559,9 +558,9 @@ int orc_qp_solve(int n, int mls, const double* Als, const double* bls, double ep
     for (int i = 0; i < n; i++) if (dreg[i] > 0) nreg++;
     int mB = mls + nreg;
     if (mB < nz) { status = 2; goto done; }
-    double* B = (double*)calloc((size_t)mB * nz, sizeof(double));
-    double* rhs = (double*)calloc(mB, sizeof(double));
-    double* QB = (double*)malloc(sizeof(double) * mB * mB);
+    double B[60 * GI_MAXN], rhs[60], QB[60 * 60];
+    if (mB > 60) { status = 2; goto done; }
+    memset(B, 0, sizeof B); memset(rhs, 0, sizeof rhs);
     for (int i = 0; i < mls; i++) {
       double s = bls[i];
       for (int j = 0; j < n; j++) s -= Als[i * n + j] * xp[j];
@@ -624,7 +623,6 @@ int orc_qp_solve(int n, int mls, const double* Als, const double* bls, double ep
         x[i] = s;
       }
     }
-    free(B); free(rhs); free(QB);
   }
 done:
   if (status == 2 && primal_res) *primal_res = INFINITY;
@@ -642,7 +640,6 @@ done:
     }
     *primal_res = res;
   }
-  free(At); free(Q); free(xp);
   return status;
 }
 
@@ -746,8 +743,8 @@ static int solve_and_extract(const orc_params* p, orc_qp* qp, double* tau) {
 int orc_id_control_law(const orc_model* m, const orc_params* p, const double* q, const double* v,
                        const double* targets, const int* contact, double* tau, double* metrics,
                        orc_qp* qp_out) {
-  tick_common* T = (tick_common*)malloc(sizeof(tick_common));
-  orc_qp* qp = qp_out ? qp_out : (orc_qp*)malloc(sizeof(orc_qp));
+  tick_common Ts, *T = &Ts;
+  orc_qp qps, *qp = qp_out ? qp_out : &qps;
   tick_head(m, q, v, targets, contact, T);
   int nc = T->nc, ns = T->ns, n = 30 + 3 * nc;
   /* :187-197 desired task-space accelerations */
@@ -807,8 +804,6 @@ int orc_id_control_law(const orc_model* m, const orc_params* p, const double* q,
       err += a * a;
     }
   if (metrics) { metrics[0] = 0; metrics[1] = err; metrics[2] = qp->primal_res; metrics[3] = 0; }
-  if (!qp_out) free(qp);
-  free(T);
   return status;
 }
 
@@ -816,8 +811,8 @@ int orc_id_control_law(const orc_model* m, const orc_params* p, const double* q,
 int orc_mptc_control_law(const orc_model* m, const orc_params* p, const double* q, const double* v,
                          const double* targets, const int* contact, double* tau, double* metrics,
                          orc_qp* qp_out) {
-  tick_common* T = (tick_common*)malloc(sizeof(tick_common));
-  orc_qp* qp = qp_out ? qp_out : (orc_qp*)malloc(sizeof(orc_qp));
+  tick_common Ts, *T = &Ts;
+  orc_qp qps, *qp = qp_out ? qp_out : &qps;
   tick_head(m, q, v, targets, contact, T);
   int nc = T->nc, ns = T->ns, n = 30 + 3 * nc, mt = 6 + 3 * ns, nf = 3 * ns;
   double C[18 * 18];
@@ -922,8 +917,6 @@ int orc_mptc_control_law(const orc_model* m, const orc_params* p, const double* 
     if (status == 2) { metrics[3] = 0; }
   }
   (void)tmp;
-  if (!qp_out) free(qp);
-  free(T);
   return status;
 }
 
