@@ -11,6 +11,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/wbc.h"
 #ifdef WBC_STAMPS
@@ -145,6 +146,13 @@ struct QuadDev {
     x = fmax(x, dpp<0x4E>(x));
     return x;
   }
+  __device__ __forceinline__ bool wave_all(bool b) const { return __all(b); }  // over the active lanes
+  __device__ __forceinline__ int wave_max_int(int x) const {  // wave-uniform maximum over the active lanes
+    int m = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) m |= (__any((x >> b) & 1) ? 1 : 0) << b;  // q <= 12: an upper bound is enough
+    return m;
+  }
   __device__ __forceinline__ bool any(bool b) const {
     int x = b ? 1 : 0;
     x |= dppi<0xB1>(x);
@@ -161,6 +169,10 @@ struct QuadDev {
 };
 
 constexpr int QROBOTS = BLOCK / 4;  // robots per 64-lane block
+constexpr int NIN = 19 + 18 + 54;    // input rows per robot (q, v, targets)
+constexpr int MODEL_PAD_WORDS = 256;  // ModelC padded to 2 KB (multiple of BLOCK 8-byte words)
+constexpr int MODEL_REPLICAS = 256;   // per-block replicas of the model table in HBM
+static_assert(sizeof(wbc::ModelC) <= MODEL_PAD_WORDS * 8 && MODEL_PAD_WORDS % BLOCK == 0, "model padding");
 
 // Per-leg kinematics cache in LDS, element-major / lane-minor (element e of lane t at
 // arena[e*64 + t]): 64 consecutive doubles per element => ds_read/write_b64 are conflict-free.
@@ -192,13 +204,23 @@ struct LegKinLds {
 // Cold per-lane stage in LDS (same element-major layout).  Reads are volatile: a plain load would be
 // store-to-load forwarded, i.e. the value would stay in a register (or be spilled to scratch).
 struct StageLds {
-  double* a;  // stage base + lane
+  double* a;        // stage base + lane (writes)
+  const double* r;  // the same address laundered through an empty asm (reads): the compiler cannot
+                    // forward the stored values (they would stay in registers or be spilled to
+                    // scratch) yet the loads stay ordinary, schedulable LDS loads (unlike volatile)
+  __device__ __forceinline__ explicit StageLds(double* p) : a(p) {
+    const double* q = p;
+    asm volatile("" : "+v"(q));
+    r = q;
+  }
   __device__ __forceinline__ void put(int i, double v) { a[i * BLOCK] = v; }
 #ifndef WBC_STAGE_VOLATILE
-#define WBC_STAGE_VOLATILE 1
+#define WBC_STAGE_VOLATILE 2
 #endif
-#if WBC_STAGE_VOLATILE
+#if WBC_STAGE_VOLATILE == 1
   __device__ __forceinline__ double get(int i) const { return *(volatile const double*)(a + i * BLOCK); }
+#elif WBC_STAGE_VOLATILE == 2
+  __device__ __forceinline__ double get(int i) const { return r[i * BLOCK]; }
 #else
   __device__ __forceinline__ double get(int i) const { return a[i * BLOCK]; }
 #endif
@@ -223,7 +245,7 @@ wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
                 int32_t* __restrict__ status, StatsDev* __restrict__ stats) {
 #if WBC_STAGE_IN_LDS
   __shared__ double arena[KIN_DOUBLES + STAGE_DOUBLES + SHQ_DOUBLES];
-  StageLds stage{arena + KIN_DOUBLES + threadIdx.x};
+  StageLds stage(arena + KIN_DOUBLES + threadIdx.x);
   wbc::QuadShared* shq = reinterpret_cast<wbc::QuadShared*>(arena + KIN_DOUBLES + STAGE_DOUBLES);
 #else
   static_assert(SHQ_DOUBLES <= KIN_DOUBLES, "active-set block must fit the kinematics arena it aliases");
@@ -236,14 +258,47 @@ wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
   const int i = blockIdx.x * QROBOTS + slot;
   const bool live = i < n;
   const int ii = live ? i : (n - 1);
-  const wbc::ModelC& m = *mp;
+  // The model table is indexed per LANE (leg = lane & 3).  Read from one global copy that is ~50
+  // dependent vector loads which all 256 CUs issue against the same 14 cache lines at the same
+  // time: measured 18 us of the 78 us tick at N = 4096 (hot-line contention; profiles/r01/cuts.md).
+  // Instead: one batched cooperative copy into LDS from a PER-BLOCK replica (MODEL_REPLICAS copies
+  // in HBM, 2 KB apart), so concurrent blocks hit different lines/channels.
+  __shared__ double mbuf[MODEL_PAD_WORDS];
+  {
+    const double* src = reinterpret_cast<const double*>(mp) + (size_t)(blockIdx.x % MODEL_REPLICAS) * MODEL_PAD_WORDS;
+    double t[MODEL_PAD_WORDS / BLOCK];
+#pragma unroll
+    for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) t[j] = src[j * BLOCK + threadIdx.x];
+#pragma unroll
+    for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) mbuf[j * BLOCK + threadIdx.x] = t[j];
+  }
+  const wbc::ModelC& m = *reinterpret_cast<const wbc::ModelC*>(mbuf);
   const wbc::ParamsC& P = *pp;
   QuadDev qo;
-  auto in = [&](int r) -> double {
-    if (r < 19) return q[(size_t)r * ld + ii];
-    if (r < 37) return v[(size_t)(r - 19) * ld + ii];
-    return tg[(size_t)(r - 37) * ld + ii];
-  };
+  // Cooperative input staging: all 91 rows x 16 robots of this block are fetched by 23 independent,
+  // 128-B-coalesced loads per lane (one HBM latency for the whole tick) and parked in LDS.  Left to
+  // itself the compiler drip-feeds the ~46 rows a lane needs (load, wait, spill; profiles/r01).
+  __shared__ double inbuf[NIN * QROBOTS];
+  {
+    constexpr int PER_LANE = (NIN * QROBOTS + BLOCK - 1) / BLOCK;
+    double tmp[PER_LANE];
+    const int r0 = blockIdx.x * QROBOTS;
+#pragma unroll
+    for (int j = 0; j < PER_LANE; j++) {
+      const int idx = j * BLOCK + threadIdx.x;
+      const int row = idx / QROBOTS, sl = idx % QROBOTS;
+      const int rob = min(r0 + sl, n - 1);
+      const double* src = row < 19 ? q + (size_t)row * ld : (row < 37 ? v + (size_t)(row - 19) * ld : tg + (size_t)(row - 37) * ld);
+      tmp[j] = (idx < NIN * QROBOTS) ? src[rob] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < PER_LANE; j++) {
+      const int idx = j * BLOCK + threadIdx.x;
+      if (idx < NIN * QROBOTS) inbuf[idx] = tmp[j];
+    }
+    __syncthreads();
+  }
+  auto in = [&](int r) -> double { return inbuf[r * QROBOTS + slot]; };
   double tsum = 0.0, tmax = 0.0, errv = 0.0;
   auto ot = [&](int k, double x) {
     if (live) tau[(size_t)k * ld + ii] = x;
@@ -342,10 +397,17 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
   h->torque_box = P.tau_max < 1e300;
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->own_stream = true;
-  HIP_TRY(hipMalloc(&h->d_model, sizeof m));
+  HIP_TRY(hipMalloc(&h->d_model, (size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8));
   HIP_TRY(hipMalloc(&h->d_params, sizeof P));
   HIP_TRY(hipMalloc(&h->d_stats, sizeof(StatsDev)));
-  HIP_TRY(hipMemcpy(h->d_model, &m, sizeof m, hipMemcpyHostToDevice));
+  {
+    // MODEL_REPLICAS padded copies (the lane-per-robot kernel reads replica 0 through a ModelC*)
+    char* rep = new char[(size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8]();
+    for (int r = 0; r < MODEL_REPLICAS; r++) memcpy(rep + (size_t)r * MODEL_PAD_WORDS * 8, &m, sizeof m);
+    hipError_t e = hipMemcpy(h->d_model, rep, (size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8, hipMemcpyHostToDevice);
+    delete[] rep;
+    if (e != hipSuccess) return fail("hipMemcpy(model replicas)", e);
+  }
   HIP_TRY(hipMemcpy(h->d_params, &P, sizeof P, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(h->d_stats, 0, sizeof(StatsDev)));
   HIP_TRY(hipEventCreate(&h->ev0));
@@ -394,22 +456,23 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
   // which only the lane-per-robot kernel implements.
   const bool quad = (h->variant == 2) || (h->variant == 0 && !h->torque_box);
   dim3 block(BLOCK);
+  StatsDev* d_stats = getenv("WBC_NO_STATS") ? nullptr : h->d_stats;  // diagnostic switch
   if (quad) {
     dim3 grid((n + QROBOTS - 1) / QROBOTS);
     if (h->kind == WBC_KIND_ID)
       hipLaunchKernelGGL(wbc_quad_kernel<wbc::KIND_ID>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q,
-                         v, tg, mask, mu, ms, tau, met, status, h->d_stats);
+                         v, tg, mask, mu, ms, tau, met, status, d_stats);
     else
       hipLaunchKernelGGL(wbc_quad_kernel<wbc::KIND_MPTC>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld,
-                         q, v, tg, mask, mu, ms, tau, met, status, h->d_stats);
+                         q, v, tg, mask, mu, ms, tau, met, status, d_stats);
   } else {
     dim3 grid((n + BLOCK - 1) / BLOCK);
     if (h->kind == WBC_KIND_ID)
       hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_ID>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q,
-                         v, tg, mask, mu, ms, tau, met, status, h->d_stats);
+                         v, tg, mask, mu, ms, tau, met, status, d_stats);
     else
       hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_MPTC>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld,
-                         q, v, tg, mask, mu, ms, tau, met, status, h->d_stats);
+                         q, v, tg, mask, mu, ms, tau, met, status, d_stats);
   }
   HIP_TRY(hipGetLastError());
   return 0;

@@ -75,155 +75,187 @@ WBC_HD void quad_qr_append(Q& qo, int l, double (*R)[3], double* rhsR, double (*
   }
 }
 
+// Dual part of one active-set step for an active set of size q <= QB: r = Rq^-1 d1, the
+// blocking multiplier (ldrop, t1 = t1n/t1d) -- replicated on the quad.  Specialised by a bound
+// on q because the wavefront's instruction count is the latency: typical trot ticks have q <= 3.
+template <int QB>
+WBC_HD void gi_dual(const QuadShared& sh, int q, const double* d, double* r, int& ldrop, double& t1n, double& t1d) {
+#pragma unroll
+  for (int k = NZ - 1; k >= QB; k--) r[k] = 0.0;
+#pragma unroll
+  for (int k = QB - 1; k >= 0; k--) {
+    double s = d[k];
+#pragma unroll
+    for (int j = k + 1; j < QB; j++) s -= ((j < q) ? sh.Rq[k][j] : 0.0) * r[j];
+    r[k] = (k < q) ? s * sh.Rq[k][k] : 0.0;  // the diagonal slot holds the RECIPROCAL pivot
+  }
+  ldrop = -1; t1n = 0.0; t1d = 1.0;
+#pragma unroll
+  for (int k = 0; k < QB; k++) {
+    if (k < q && r[k] > 0.0) {
+      const double uk = sh.u[k];
+      if (ldrop < 0 || uk * t1d < t1n * r[k]) { t1n = uk; t1d = r[k]; ldrop = k; }
+    }
+  }
+}
+
 // Goldfarb-Idnani on the friction rows.  Jr = rows 3l..3l+2 of J (J J' = H^-1), zl = own 3
 // entries of z.  Constraint index p = 4*leg + row.
+//
+// SIMT shape: ONE flat loop; in every trip each unfinished robot of the wavefront performs exactly
+// one step of the algorithm (pick the most violated row if it has none in hand, then one
+// primal/dual step ending in an add or a drop).  The textbook nested loops make the 16 robots of a
+// wavefront diverge into different loop bodies and serialise (measured 6 us per step); here the
+// trip count is the maximum over the robots, not the sum.
 template <class Q>
 WBC_HD int quad_gi(Q& qo, int l, bool ct, double (*Jr)[NZ], double* zl, double mu_n, double inv_s, QuadShared& sh,
                    int* iters_out) {
-  int q = 0, iters = 0;
+  int q = 0, iters = 0, status = ST_OK;
   unsigned active = 0u;
   const int maxit = 200;
-  for (;;) {
-    double zinf = fmax(fabs(zl[0]), fmax(fabs(zl[1]), fabs(zl[2])));
-    zinf = qo.max(zinf);
-    const double tol = 1e-13 * (1.0 + zinf);
-    double sp = -tol;
-    int p = -1;
-    if (ct) {
+  bool done = false, need_pick = true;
+  int p = -1;
+  double sp = 0.0;
+  double npl[3] = {0.0, 0.0, 0.0};
+  for (int trip = 0; trip < maxit; trip++) {
+    if (!done && need_pick) {
+      double zinf = fmax(fabs(zl[0]), fmax(fabs(zl[1]), fabs(zl[2])));
+      zinf = qo.max(zinf);
+      const double tol = 1e-13 * (1.0 + zinf);
+      sp = -tol;
+      p = -1;
+      if (ct) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        if ((active >> (4 * l + r)) & 1u) continue;
-        const double zc = (r >> 1) ? zl[1] : zl[0];
-        const double s = ((r & 1) ? inv_s : -inv_s) * zc + mu_n * zl[2];
-        if (s < sp) { sp = s; p = 4 * l + r; }
-      }
-    }
-    qo.argmin(sp, p);
-    if (p < 0) { *iters_out = iters; return ST_OK; }
-    const int owner = p >> 2, rr = p & 3;
-    double npl[3] = {0.0, 0.0, 0.0};
-    if (l == owner) {
-      const double sg = (rr & 1) ? inv_s : -inv_s;
-      npl[0] = (rr >> 1) ? 0.0 : sg;
-      npl[1] = (rr >> 1) ? sg : 0.0;
-      npl[2] = mu_n;
-    }
-    sh.u[q] = 0.0;
-    for (;;) {
-      if (++iters > maxit) { *iters_out = iters; return ST_ITER; }
-      double d[NZ], dn = 0.0, d2n = 0.0;
-#pragma unroll
-      for (int k = 0; k < NZ; k++) {
-        d[k] = qo.sum(Jr[0][k] * npl[0] + Jr[1][k] * npl[1] + Jr[2][k] * npl[2]);
-        dn += d[k] * d[k];
-        if (k >= q) d2n += d[k] * d[k];
-      }
-      double zd[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-      for (int k = 0; k < NZ; k++) {
-        const double dk = (k >= q) ? d[k] : 0.0;
-        zd[0] += Jr[0][k] * dk; zd[1] += Jr[1][k] * dk; zd[2] += Jr[2][k] * dk;
-      }
-      // r = Rq^-1 d1 (replicated); entries >= q are zero
-      double r[NZ];
-#pragma unroll
-      for (int k = NZ - 1; k >= 0; k--) {
-        double s = d[k];
-#pragma unroll
-        for (int j = k + 1; j < NZ; j++) s -= ((j < q) ? sh.Rq[k][j] : 0.0) * r[j];
-        r[k] = (k < q) ? s / sh.Rq[k][k] : 0.0;
-      }
-      int ldrop = -1;
-      double t1n = 0.0, t1d = 1.0;  // t1 = t1n / t1d, compared by cross-multiplication
-#pragma unroll
-      for (int k = 0; k < NZ; k++) {
-        if (k < q && r[k] > 0.0) {
-          const double uk = sh.u[k];
-          if (ldrop < 0 || uk * t1d < t1n * r[k]) { t1n = uk; t1d = r[k]; ldrop = k; }
+        for (int r = 0; r < 4; r++) {
+          const bool act = (active >> (4 * l + r)) & 1u;
+          const double zc = (r >> 1) ? zl[1] : zl[0];
+          const double s = ((r & 1) ? inv_s : -inv_s) * zc + mu_n * zl[2];
+          if (!act && s < sp) { sp = s; p = 4 * l + r; }
         }
       }
-      const bool have_t1 = ldrop >= 0;
-      const double t1 = have_t1 ? t1n / t1d : 0.0;
-      const bool dependent = !(d2n > 1e-22 * dn) || q == NZ;
-      double t2 = 0.0;
-      if (!dependent) {
-        const double znp = qo.sum(zd[0] * npl[0] + zd[1] * npl[1] + zd[2] * npl[2]);
-        t2 = -sp / znp;
+      qo.argmin(sp, p);
+      if (p < 0) {
+        done = true;
+      } else {
+        const int owner = p >> 2, rr = p & 3;
+        const double sg = (rr & 1) ? inv_s : -inv_s;
+        const bool mine = (l == owner);
+        npl[0] = (mine && !(rr >> 1)) ? sg : 0.0;
+        npl[1] = (mine && (rr >> 1)) ? sg : 0.0;
+        npl[2] = mine ? mu_n : 0.0;
+        sh.u[q] = 0.0;
+        need_pick = false;
       }
-      if (dependent && !have_t1) { *iters_out = iters; return ST_SINGULAR; }
-      const bool full = !dependent && (!have_t1 || !(t1 < t2));
-      const double t = full ? t2 : t1;
+    }
+    if (qo.wave_all(done)) break;
+    if (done) continue;
+    iters++;
+    double d[NZ], dn = 0.0, d2n = 0.0;
+#pragma unroll
+    for (int k = 0; k < NZ; k++) {
+      d[k] = qo.sum(Jr[0][k] * npl[0] + Jr[1][k] * npl[1] + Jr[2][k] * npl[2]);
+      dn += d[k] * d[k];
+      if (k >= q) d2n += d[k] * d[k];
+    }
+    double zd[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NZ; k++) {
+      const double dk = (k >= q) ? d[k] : 0.0;
+      zd[0] += Jr[0][k] * dk; zd[1] += Jr[1][k] * dk; zd[2] += Jr[2][k] * dk;
+    }
+    // r = Rq^-1 d1 and the blocking multiplier, by a wave-uniform bound on the active-set size
+    double r[NZ];
+    int ldrop;
+    double t1n, t1d;
+    const int qmax = qo.wave_max_int(q);
+    if (qmax <= 3) gi_dual<3>(sh, q, d, r, ldrop, t1n, t1d);
+    else if (qmax <= 6) gi_dual<6>(sh, q, d, r, ldrop, t1n, t1d);
+    else gi_dual<NZ>(sh, q, d, r, ldrop, t1n, t1d);
+    const bool have_t1 = ldrop >= 0;
+    const double t1 = have_t1 ? t1n / t1d : 0.0;
+    const bool dependent = !(d2n > 1e-22 * dn) || q == NZ;
+    const double znp = qo.sum(zd[0] * npl[0] + zd[1] * npl[1] + zd[2] * npl[2]);
+    const double t2 = dependent ? 0.0 : -sp / znp;
+    if (dependent && !have_t1) { status = ST_SINGULAR; done = true; continue; }
+    const bool full = !dependent && (!have_t1 || !(t1 < t2));
+    const double t = full ? t2 : t1;
+#pragma unroll
+    for (int k = 0; k < NZ; k++)
+      if (k < q) sh.u[k] -= t * r[k];
+    sh.u[q] += t;
+    if (!dependent) { zl[0] += t * zd[0]; zl[1] += t * zd[1]; zl[2] += t * zd[2]; }
+    if (full) {
+      // one Householder reflection H on d[q:] (H d2 = alpha e1); J2 <- J2 H on the own rows
+      double dq = 0.0;
+#pragma unroll
+      for (int k = 0; k < NZ; k++) dq = (k == q) ? d[k] : dq;
+      const double nrm = sqrt(d2n);
+      const double alpha = (dq > 0.0) ? -nrm : nrm;
+      const double vq = dq - alpha;
+      const double vv = d2n - dq * dq + vq * vq;
+      if (vv > 0.0) {
+        const double beta = 2.0 / vv;
+        double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+        double hv[NZ];
+#pragma unroll
+        for (int k = 0; k < NZ; k++) {
+          hv[k] = (k < q) ? 0.0 : ((k == q) ? vq : d[k]);
+          w0 += Jr[0][k] * hv[k]; w1 += Jr[1][k] * hv[k]; w2 += Jr[2][k] * hv[k];
+        }
+        w0 *= beta; w1 *= beta; w2 *= beta;
+#pragma unroll
+        for (int k = 0; k < NZ; k++) {
+          Jr[0][k] -= w0 * hv[k]; Jr[1][k] -= w1 * hv[k]; Jr[2][k] -= w2 * hv[k];
+        }
+      }
 #pragma unroll
       for (int k = 0; k < NZ; k++)
-        if (k < q) sh.u[k] -= t * r[k];
-      sh.u[q] += t;
-      if (!dependent) { zl[0] += t * zd[0]; zl[1] += t * zd[1]; zl[2] += t * zd[2]; }
-      if (full) {
-        // one Householder reflection H on d[q:] (H d2 = alpha e1); J2 <- J2 H on the own rows
-        double dq = 0.0;
-#pragma unroll
-        for (int k = 0; k < NZ; k++) dq = (k == q) ? d[k] : dq;
-        const double nrm = sqrt(d2n);
-        const double alpha = (dq > 0.0) ? -nrm : nrm;
-        const double vq = dq - alpha;
-        const double vv = d2n - dq * dq + vq * vq;
-        if (vv > 0.0) {
-          const double beta = 2.0 / vv;
-          double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-          double hv[NZ];
-#pragma unroll
-          for (int k = 0; k < NZ; k++) {
-            hv[k] = (k < q) ? 0.0 : ((k == q) ? vq : d[k]);
-            w0 += Jr[0][k] * hv[k]; w1 += Jr[1][k] * hv[k]; w2 += Jr[2][k] * hv[k];
-          }
-          w0 *= beta; w1 *= beta; w2 *= beta;
-#pragma unroll
-          for (int k = 0; k < NZ; k++) {
-            Jr[0][k] -= w0 * hv[k]; Jr[1][k] -= w1 * hv[k]; Jr[2][k] -= w2 * hv[k];
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < NZ; k++)
-          if (k < q) sh.Rq[k][q] = d[k];
-        sh.Rq[q][q] = alpha;
-        sh.A[q] = p;
-        active |= (1u << p);
-        q++;
-        break;
-      }
-      // partial / pure dual step: drop active constraint ldrop
-      active &= ~(1u << sh.A[ldrop]);
-      for (int j = ldrop; j < q - 1; j++) {
-        sh.A[j] = sh.A[j + 1];
-        sh.u[j] = sh.u[j + 1];
-        for (int k = 0; k <= j + 1; k++) sh.Rq[k][j] = sh.Rq[k][j + 1];
-      }
-      sh.u[q - 1] = sh.u[q];
-      q--;
-      sh.u[q + 1] = 0.0;
-      for (int j = ldrop; j < q; j++) {
-        const double a = sh.Rq[j][j], bb = sh.Rq[j + 1][j];
-        if (bb == 0.0) continue;
-        const double h = sqrt(a * a + bb * bb), c = a / h, s = bb / h;
-        for (int k = j; k < q; k++) {
-          const double x = sh.Rq[j][k], y = sh.Rq[j + 1][k];
-          sh.Rq[j][k] = c * x + s * y;
-          sh.Rq[j + 1][k] = c * y - s * x;
-        }
-#pragma unroll
-        for (int jj = 0; jj < NZ - 1; jj++) {
-          if (jj != j) continue;
-#pragma unroll
-          for (int i = 0; i < 3; i++) {
-            const double x = Jr[i][jj], y = Jr[i][jj + 1];
-            Jr[i][jj] = c * x + s * y;
-            Jr[i][jj + 1] = c * y - s * x;
-          }
-        }
-      }
-      if (!dependent) sp = qo.sum(npl[0] * zl[0] + npl[1] * zl[1] + npl[2] * zl[2]);
+        if (k < q) sh.Rq[k][q] = d[k];
+      sh.Rq[q][q] = 1.0 / alpha;
+      sh.A[q] = p;
+      active |= (1u << p);
+      q++;
+      need_pick = true;
+      continue;
     }
+    // partial / pure dual step: drop active constraint ldrop
+    active &= ~(1u << sh.A[ldrop]);
+    for (int j = ldrop; j < q - 1; j++) {
+      sh.A[j] = sh.A[j + 1];
+      sh.u[j] = sh.u[j + 1];
+      for (int k = 0; k <= j + 1; k++) sh.Rq[k][j] = sh.Rq[k][j + 1];
+    }
+    sh.u[q - 1] = sh.u[q];
+    q--;
+    sh.u[q + 1] = 0.0;
+    for (int j = ldrop; j < q; j++) {
+      // After the shift, column j (>= ldrop) holds the old column j+1 verbatim: rows 0..j are plain
+      // values (including the new "diagonal" (j,j)) and row j+1 is the old pivot, stored as its
+      // reciprocal.  Rotate rows j, j+1 to kill that sub-diagonal entry.
+      const double a = sh.Rq[j][j], bb = 1.0 / sh.Rq[j + 1][j];
+      const double h = sqrt(a * a + bb * bb), c = a / h, sn = bb / h;
+      sh.Rq[j][j] = 1.0 / h;
+      for (int k = j + 1; k < q; k++) {
+        const double x = sh.Rq[j][k], y = sh.Rq[j + 1][k];
+        sh.Rq[j][k] = c * x + sn * y;
+        sh.Rq[j + 1][k] = c * y - sn * x;
+      }
+#pragma unroll
+      for (int jj = 0; jj < NZ - 1; jj++) {
+        if (jj != j) continue;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const double x = Jr[i][jj], y = Jr[i][jj + 1];
+          Jr[i][jj] = c * x + sn * y;
+          Jr[i][jj + 1] = c * y - sn * x;
+        }
+      }
+    }
+    if (!dependent) sp = qo.sum(npl[0] * zl[0] + npl[1] * zl[1] + npl[2] * zl[2]);
   }
+  *iters_out = iters;
+  if (!done && status == ST_OK) status = ST_ITER;
+  return status;
 }
 
 // 6x6 solve with partial pivoting for NR right-hand sides held as extra columns: Ab = [G | rhs].
@@ -269,6 +301,22 @@ template <int NR> WBC_HD double solve6(double (*Ab)[6 + NR]) {
   return pmin / pmax;
 }
 
+// Diagnostic builds only (-DWBC_CUT=k): return after phase k, folding the live values into the
+// output so the truncated phases are not dead-code-eliminated.  Timing such builds as whole
+// kernels gives a phase attribution that the optimiser cannot blur (unlike in-kernel stamps).
+#ifdef WBC_CUT
+#define WBC_CUT_AT(k, expr)                                                        \
+  if (WBC_CUT == (k)) {                                                            \
+    double sink_ = (expr);                                                         \
+    for (int k_ = 0; k_ < 3; k_++) out_tau(m.act_inv[3 * l + k_], sink_);          \
+    out_met(0, sink_); out_met(1, sink_); out_met(2, 0.0); out_met(3, 0.0);        \
+    *iters_out = 0;                                                                \
+    return ST_OK;                                                                  \
+  }
+#else
+#define WBC_CUT_AT(k, expr)
+#endif
+
 // The tick.  Every lane of the quad calls this with its own Q (lane id = leg).
 // out_tau(row, x): lane l writes the output rows of its own three joints;  out_met: lane 0 only.
 //
@@ -278,7 +326,7 @@ template <int NR> WBC_HD double solve6(double (*Ab)[6 + NR]) {
 // Cold per-lane storage ("stage"): values written in the leg phase and only needed again much later
 // (torque-map build, MPTC assembly, output) are parked in LDS instead of occupying registers for
 // the whole tick.  Slots in doubles.
-enum { ST_Y = 0, ST_PM = 18, ST_JL = 27, ST_JI = 36, ST_JD = 45, ST_MLL = 54, ST_MTBL = 60, ST_MTLL = 78, ST_N = 87 };
+enum { ST_Y = 0, ST_PM = 18, ST_JL = 27, ST_JI = 36, ST_JD = 45, ST_MLL = 54, ST_B = 60, ST_AB0 = 78, ST_N = 84 };
 
 // Read of a quad-shared (replicated-write) LDS value.  A volatile read (forcing a real LDS load)
 // was measured 10 % SLOWER than letting the compiler forward the stored value (profiles/r01).
@@ -296,6 +344,7 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
   const bool ct = (mask >> l) & 1u;
   int status = ST_OK;
   WBC_STAMP(0);
+  WBC_CUT_AT(11, in(0) + in(20) + in(40) + in(37 + 18 + 9 * l) + mu + mass_scale)
   // ---------------- state (replicated on the 4 lanes)
   double R0[9];
   {
@@ -361,6 +410,7 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
       }
     }
   }
+  WBC_CUT_AT(12, xt_b[0] + xt_b[4] + xdt_b[1] + xdt_b[5] + xdd_b[2] + ades[1] + bI[3] + bmc[1] + R0[5] + rpyd[0] + E[3])
   WBC_STAMP(1);
   // ---------------- own leg: FK, Newton-Euler bias pass, composite inertia, foot Jacobian
   double rf[3], Jdv[3], pd[3], rd[3], hl[3];
@@ -374,6 +424,7 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
     LegDyn<double> D;
     double qd[3];
     double Jl[9], Ji[9], Y[18], Pm[9];
+    const double mass3[3] = {m.link[l][0].mass, m.link[l][1].mass, m.link[l][2].mass};
     {
       double sn[3], cs[3];
       for (int k = 0; k < 3; k++) {
@@ -382,13 +433,15 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
         wbc_sincos(th, sn[k], cs[k]);
         qd[k] = in(25 + row);
       }
+      WBC_CUT_AT(13, sn[0] + sn[1] + sn[2] + cs[0] + cs[1] + cs[2] + qd[1] + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1] + bI[3] + R0[5])
       leg_fk(m, l, R0, sn, cs, K);
     }
+    WBC_CUT_AT(7, K.rf(0) + K.r(1, 1) + K.Iw(2, 3) + K.mcw(0, 2) + K.ax(2, 0) + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1] + qd[0])
     WBC_STAMP(2);
     {
       const KinT& Kc = K;
-      leg_rnea<double, true>(m, l, Kc, w0, qd, gz, hl, hbN, hbN + 3, &D);
-      leg_crba(m, l, Kc, D, lm, lh, lI);
+      leg_rnea<double, true>(mass3, Kc, w0, qd, gz, hl, hbN, hbN + 3, &D);
+      leg_crba(mass3, Kc, D, lm, lh, lI);
     }
     WBC_STAMP(3);
     for (int i = 0; i < 3; i++) { rf[i] = K.rf(i); Jdv[i] = D.Jdv[i]; rd[i] = D.rd[i]; pd[i] = v0[i] + D.rd[i]; }
@@ -405,6 +458,7 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
     double Mf[9];
     sym_to_full(D.Mll, Mf);
     mm3(Mf, Ji, Pm);  // Pm = Mll Ji
+    WBC_CUT_AT(8, Pm[0] + Pm[8] + Ji[4] + Jl[2] + D.Mbl[7] + D.Jd[3] + Jdv[1] + rd[2] + hl[0] + hbN[4] + lm + lh[0] + lI[5] + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1])
     // own foot targets / errors (zero for a contact leg)
     for (int i = 0; i < 3; i++) {
       const double pf = p0[i] + rf[i];
@@ -435,6 +489,7 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
         const double y[3] = {xdt_s[0] - jfb[0], xdt_s[1] - jfb[1], xdt_s[2] - jfb[2]};
         rotv(Ji, y, xi);
       }
+      WBC_CUT_AT(9, xi[0] + xi[1] + xi[2] + Pm[0] + Ji[4] + Jl[2] + D.Mbl[7] + D.Jd[3] + Jdv[1] + rd[2] + hl[0] + hbN[4] + lm + lh[0] + lI[5] + xt_b[0] + xdd_b[2])
       // C xi = 1/4 [h(v + xi) - h(v - xi)]  (two more Newton-Euler passes over the cached kinematics)
       const KinT& Kc = K;
       for (int sgi = 0; sgi < 2; sgi++) {
@@ -442,10 +497,11 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
         const double wv[3] = {w0[0] + s1 * xdt_b[0], w0[1] + s1 * xdt_b[1], w0[2] + s1 * xdt_b[2]};
         const double qv[3] = {qd[0] + s1 * xi[0], qd[1] + s1 * xi[1], qd[2] + s1 * xi[2]};
         double hl2[3], Nb[3], Fb[3];
-        leg_rnea<double, false>(m, l, Kc, wv, qv, 0.0, hl2, Nb, Fb, (LegDyn<double>*)nullptr);
+        leg_rnea<double, false>(mass3, Kc, wv, qv, 0.0, hl2, Nb, Fb, (LegDyn<double>*)nullptr);
         for (int i = 0; i < 3; i++) { Cb_leg[i] += sg * Nb[i]; Cb_leg[3 + i] += sg * Fb[i]; Cl[i] += sg * hl2[i]; }
       }
     }
+    WBC_CUT_AT(10, Cb_leg[0] + Cb_leg[4] + Cl[1] + xi[0] + Pm[0] + Ji[4] + Jl[2] + D.Mbl[7] + D.Jd[3] + Jdv[1] + rd[2] + hl[0] + hbN[4] + lm + lh[0] + lI[5] + xt_b[0] + xdd_b[2])
     WBC_STAMP(4);
     // X = Mbl Ji, Y = Mbl' - Pm Jfb
     for (int i = 0; i < 6; i++)
@@ -471,6 +527,7 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
   }  // D dead; K (the kinematics arena) is not read again: its storage may alias `sh`
   const double bc[3] = {ct ? (-P.Kd_contact * pd[0] - Jdv[0]) : 0.0, ct ? (-P.Kd_contact * pd[1] - Jdv[1]) : 0.0,
                         ct ? (-P.Kd_contact * pd[2] - Jdv[2]) : 0.0};
+  WBC_CUT_AT(1, X[0] + X[7] + X[17] + hbN[0] + hbN[5] + lm + lh[1] + lI[3] + Cb_leg[2] + Cl[1] + xi[0] + t0l[0] + t0l[2] + st.get(ST_Y + 3) + st.get(ST_JL + 4) + st.get(ST_JD + 2) + xt_s[0] + xdt_s[1])
   WBC_STAMP(5);
   // ---------------- base: bias wrench, composite inertia -> Gs = G_b, kv
   double Gs[6][6], kv[6];
@@ -532,8 +589,13 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
     const double rc = solve6<4>(Ab);
     if (!(rc > 1e-12)) status = ST_SINGULAR;
     for (int i = 0; i < 6; i++) { B[i][0] = Ab[i][6]; B[i][1] = Ab[i][7]; B[i][2] = Ab[i][8]; ab0[i] = Ab[i][9]; }
+    for (int i = 0; i < 6; i++) {
+      st.put(ST_AB0 + i, ab0[i]);
+      for (int j = 0; j < 3; j++) st.put(ST_B + 3 * i + j, B[i][j]);
+    }
   }
 
+  WBC_CUT_AT(2, B[0][0] + B[3][1] + B[5][2] + ab0[0] + ab0[5] + Gs[2][3] + Cb_leg[2] + Cl[1] + xi[0] + t0l[1] + st.get(ST_Y + 3))
   WBC_STAMP(7);
   // ---------------- level-1 rows
   const double eps = sqrt(P.eps2);
@@ -572,44 +634,28 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
     quad_qr_append<Q, 6>(qo, l, Rc, rhsR, blk, brhs);
   } else {
     // ---- MPTC in task coordinates (derivation: wbc_tick.hpp / DESIGN.md)
-    // Register diet: Lambda_bb (replicated 6x6) is parked in the quad-shared LDS block (it aliases
-    // the active-set factor, which is not live yet), Mt_bl / Mt_ll in the per-lane stage.
-    double* Lsh = &sh.Rq[0][0];
+    // Register diet: Lambda_bb (a replicated 6x6) is never materialised.  Each of its rows is
+    // formed from six quad sums and consumed at once by the two Lambda*vector products and by the
+    // body least-squares row, then dropped.
+    double Y[18], Ji[9], MiY[18], Mt_bl[18], Mt_ll[9];
+    for (int i = 0; i < 18; i++) Y[i] = st.get(ST_Y + i);
+    for (int i = 0; i < 9; i++) Ji[i] = st.get(ST_JI + i);
+    {
+      double Ms[6], Mf[9], Mli[9];
+      for (int i = 0; i < 6; i++) Ms[i] = st.get(ST_MLL + i);
+      sym_to_full(Ms, Mf);
+      inv3(Mf, Mli);
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 6; j++) MiY[6 * i + j] = Mli[3 * i] * Y[j] + Mli[3 * i + 1] * Y[6 + j] + Mli[3 * i + 2] * Y[12 + j];
+    }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 6; j++) Mt_bl[3 * j + i] = Ji[i] * Y[j] + Ji[3 + i] * Y[6 + j] + Ji[6 + i] * Y[12 + j];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++)
+        Mt_ll[3 * i + j] = Ji[i] * st.get(ST_PM + j) + Ji[3 + i] * st.get(ST_PM + 3 + j) + Ji[6 + i] * st.get(ST_PM + 6 + j);
+    // Lambda (J Minv C xi): base rows replicated, own swing rows local
     double LJ_b[6], LJ_s[3];
     {
-      double Y[18], Ji[9], MiY[18];
-      for (int i = 0; i < 18; i++) Y[i] = st.get(ST_Y + i);
-      for (int i = 0; i < 9; i++) Ji[i] = st.get(ST_JI + i);
-      {
-        double Ms[6], Mf[9], Mli[9];
-        for (int i = 0; i < 6; i++) Ms[i] = st.get(ST_MLL + i);
-        sym_to_full(Ms, Mf);
-        inv3(Mf, Mli);
-        for (int i = 0; i < 3; i++)
-          for (int j = 0; j < 6; j++) MiY[6 * i + j] = Mli[3 * i] * Y[j] + Mli[3 * i + 1] * Y[6 + j] + Mli[3 * i + 2] * Y[12 + j];
-      }
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 6; j++) st.put(ST_MTBL + 3 * j + i, Ji[i] * Y[j] + Ji[3 + i] * Y[6 + j] + Ji[6 + i] * Y[12 + j]);
-      for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++)
-          st.put(ST_MTLL + 3 * i + j, Ji[i] * st.get(ST_PM + j) + Ji[3 + i] * st.get(ST_PM + 3 + j) + Ji[6 + i] * st.get(ST_PM + 6 + j));
-      {
-        double A[18];  // Ji Jfb
-        for (int i = 0; i < 3; i++) {
-          const double a0 = Ji[3 * i], a1 = Ji[3 * i + 1], a2 = Ji[3 * i + 2];
-          A[6 * i + 0] = -(a1 * rf[2] - a2 * rf[1]);
-          A[6 * i + 1] = -(a2 * rf[0] - a0 * rf[2]);
-          A[6 * i + 2] = -(a0 * rf[1] - a1 * rf[0]);
-          A[6 * i + 3] = a0; A[6 * i + 4] = a1; A[6 * i + 5] = a2;
-        }
-        for (int i = 0; i < 6; i++)
-          for (int j = 0; j < 6; j++) {
-            double c = A[i] * Y[j] + A[6 + i] * Y[6 + j] + A[12 + i] * Y[12 + j];
-            if (ct) c += Y[i] * MiY[j] + Y[6 + i] * MiY[6 + j] + Y[12 + i] * MiY[12 + j];
-            Lsh[6 * i + j] = Gs[i][j] - qo.sum(c);
-          }
-      }
-      // Lambda (J Minv C xi): base rows replicated, own swing rows local
       double Cb_base[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
       for (int sgi = 0; sgi < 2; sgi++) {
         const double sg = sgi ? -0.25 : 0.25, s1 = sgi ? -1.0 : 1.0;
@@ -640,56 +686,79 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
         s1_s[i] = ct ? 0.0 : xdd_s[i] - Jdv[i] + jx;
       }
     }
-    auto lam_mul = [&](const double* yb, const double* ys, double* ob, double* os) {
-      for (int i = 0; i < 6; i++) {
-        double s = 0.0;
-        for (int j = 0; j < 6; j++) s += WBC_SH_GET(Lsh[6 * i + j]) * yb[j];
-        const double loc = ct ? 0.0 : st.get(ST_MTBL + 3 * i) * ys[0] + st.get(ST_MTBL + 3 * i + 1) * ys[1] + st.get(ST_MTBL + 3 * i + 2) * ys[2];
-        ob[i] = s + qo.sum(loc);
-      }
-      for (int i = 0; i < 3; i++) {
-        double s = st.get(ST_MTLL + 3 * i) * ys[0] + st.get(ST_MTLL + 3 * i + 1) * ys[1] + st.get(ST_MTLL + 3 * i + 2) * ys[2];
-        for (int j = 0; j < 6; j++) s += st.get(ST_MTBL + 3 * j + i) * yb[j];
-        os[i] = ct ? 0.0 : s;
-      }
-    };
-    double c1_b[6], c1_s[3];
+    // swing parts of the two Lambda*vector products (independent of Lambda_bb)
+    double Ls_s[3], Lx_s[3];
+    for (int i = 0; i < 3; i++) {
+      double a = Mt_ll[3 * i] * s1_s[0] + Mt_ll[3 * i + 1] * s1_s[1] + Mt_ll[3 * i + 2] * s1_s[2];
+      double b = Mt_ll[3 * i] * xdt_s[0] + Mt_ll[3 * i + 1] * xdt_s[1] + Mt_ll[3 * i + 2] * xdt_s[2];
+      for (int j = 0; j < 6; j++) { a += Mt_bl[3 * j + i] * xdd_b[j]; b += Mt_bl[3 * j + i] * xdt_b[j]; }
+      Ls_s[i] = ct ? 0.0 : a;
+      Lx_s[i] = ct ? 0.0 : b;
+    }
+    double c1_s[3];
     {
-      double Ls_b[6], Ls_s[3];
-      lam_mul(xdd_b, s1_s, Ls_b, Ls_s);
-      for (int i = 0; i < 6; i++) {
-        const double kp = (i < 3) ? P.Kp_body_rpy : P.Kp_body_p, kd = (i < 3) ? P.Kd_body_rpy : P.Kd_body_p;
-        c1_b[i] = LJ_b[i] - Ls_b[i] + kp * xt_b[i] + kd * xdt_b[i];
-        met_V += 0.5 * kp * xt_b[i] * xt_b[i];
-        met_Vdot += -kd * xdt_b[i] * xdt_b[i] + xdt_b[i] * c1_b[i];
-      }
       double lv = 0.0, lvd = 0.0;
       for (int i = 0; i < 3; i++) {
         c1_s[i] = LJ_s[i] - Ls_s[i] + P.Kp_foot * xt_s[i] + P.Kd_foot * xdt_s[i];
-        lv += 0.5 * P.Kp_foot * xt_s[i] * xt_s[i];
+        lv += 0.5 * P.Kp_foot * xt_s[i] * xt_s[i] + 0.5 * xdt_s[i] * Lx_s[i];
         lvd += -P.Kd_foot * xdt_s[i] * xdt_s[i] + xdt_s[i] * c1_s[i];
       }
-      double Lx_b[6], Lx_s[3];
-      lam_mul(xdt_b, xdt_s, Lx_b, Lx_s);
-      for (int i = 0; i < 6; i++) met_V += 0.5 * xdt_b[i] * Lx_b[i];
-      for (int i = 0; i < 3; i++) lv += 0.5 * xdt_s[i] * Lx_s[i];
       met_V += qo.sum(lv);
       met_Vdot += qo.sum(lvd);
-      for (int j = 0; j < 3; j++) {
-        double s = 0.0;
-        for (int k = 0; k < 6; k++) s += Lx_b[k] * B[k][j];
-        vrow[j] = s + (ct ? 0.0 : Lx_s[j]);
+    }
+    double blk[12][3], brhs[12];
+    {
+      double A[18];  // Ji Jfb
+      for (int i = 0; i < 3; i++) {
+        const double a0 = Ji[3 * i], a1 = Ji[3 * i + 1], a2 = Ji[3 * i + 2];
+        A[6 * i + 0] = -(a1 * rf[2] - a2 * rf[1]);
+        A[6 * i + 1] = -(a2 * rf[0] - a0 * rf[2]);
+        A[6 * i + 2] = -(a0 * rf[1] - a1 * rf[0]);
+        A[6 * i + 3] = a0; A[6 * i + 4] = a1; A[6 * i + 5] = a2;
       }
-      for (int k = 0; k < 6; k++) vconst += Lx_b[k] * ab0[k];
+      for (int j = 0; j < 3; j++) vrow[j] = ct ? 0.0 : Lx_s[j];
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        double Lrow[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          double c = A[i] * Y[j] + A[6 + i] * Y[6 + j] + A[12 + i] * Y[12 + j];
+          if (ct) c += Y[i] * MiY[j] + Y[6 + i] * MiY[6 + j] + Y[12 + i] * MiY[12 + j];
+          Lrow[j] = Gs[i][j] - qo.sum(c);
+        }
+        double ls = 0.0, lx = 0.0, la = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) { ls += Lrow[j] * xdd_b[j]; lx += Lrow[j] * xdt_b[j]; la += Lrow[j] * ab0[j]; }
+        ls += qo.sum(ct ? 0.0 : Mt_bl[3 * i] * s1_s[0] + Mt_bl[3 * i + 1] * s1_s[1] + Mt_bl[3 * i + 2] * s1_s[2]);
+        lx += qo.sum(ct ? 0.0 : Mt_bl[3 * i] * xdt_s[0] + Mt_bl[3 * i + 1] * xdt_s[1] + Mt_bl[3 * i + 2] * xdt_s[2]);
+        const double kp = (i < 3) ? P.Kp_body_rpy : P.Kp_body_p, kd = (i < 3) ? P.Kd_body_rpy : P.Kd_body_p;
+        const double c1 = LJ_b[i] - ls + kp * xt_b[i] + kd * xdt_b[i];
+        met_V += 0.5 * kp * xt_b[i] * xt_b[i] + 0.5 * xdt_b[i] * lx;
+        met_Vdot += -kd * xdt_b[i] * xdt_b[i] + xdt_b[i] * c1;
+        vconst += lx * ab0[i];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          double sj = 0.0;
+#pragma unroll
+          for (int k = 0; k < 6; k++) sj += Lrow[k] * B[k][j];
+          if (!ct) sj += Mt_bl[3 * i + j];
+          blk[i][j] = sw_b * sj;
+          vrow[j] += lx * B[i][j];
+        }
+        brhs[i] = -sw_b * (c1 + la);
+      }
     }
     WBC_STAMP(8);
-    // rows of sqrt(W) Lambda [B; Sel]: 6 body rows + 3 rows per swing leg.  The first two
+    // rows of sqrt(W) Lambda [B; Sel]: 6 body rows (above) + 3 rows per swing leg.  The first two
     // swing legs share one 12-row Householder append with the body rows (the trot case);
     // further swing legs (nc < 2) go through a second 6-row append.
-    int sw_leg[4], ns = 0;
+    int sw0 = -1, sw1 = -1, sw2 = -1, sw3 = -1, ns = 0;
+#pragma unroll
     for (int lp = 0; lp < 4; lp++)
-      if (!((mask >> lp) & 1u)) sw_leg[ns++] = lp;
-    for (int lp = ns; lp < 4; lp++) sw_leg[lp] = -1;
+      if (!((mask >> lp) & 1u)) {
+        if (ns == 0) sw0 = lp; else if (ns == 1) sw1 = lp; else if (ns == 2) sw2 = lp; else sw3 = lp;
+        ns++;
+      }
     auto swing_rows = [&](int lp, double (*b3)[3], double* r3) {
       // lp is quad-uniform; lp < 0 -> zero rows
       if (lp < 0) {
@@ -698,50 +767,42 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
       }
       double Mp[18], c1p[3];
 #pragma unroll
-      for (int i = 0; i < 18; i++) Mp[i] = qo.bcast_d(st.get(ST_MTBL + i), lp);
+      for (int i = 0; i < 18; i++) Mp[i] = qo.bcast_d(Mt_bl[i], lp);
 #pragma unroll
       for (int i = 0; i < 3; i++) c1p[i] = qo.bcast_d(c1_s[i], lp);
       for (int i = 0; i < 3; i++) {
         for (int j = 0; j < 3; j++) {
-          double s = 0.0;
-          for (int k = 0; k < 6; k++) s += Mp[3 * k + i] * B[k][j];
-          if (lp == l) s += st.get(ST_MTLL + 3 * i + j);
-          b3[i][j] = sw_f * s;
+          double sj = 0.0;
+          for (int k = 0; k < 6; k++) sj += Mp[3 * k + i] * B[k][j];
+          if (lp == l) sj += Mt_ll[3 * i + j];
+          b3[i][j] = sw_f * sj;
         }
-        double s = c1p[i];
-        for (int k = 0; k < 6; k++) s += Mp[3 * k + i] * ab0[k];
-        r3[i] = -sw_f * s;
+        double sj = c1p[i];
+        for (int k = 0; k < 6; k++) sj += Mp[3 * k + i] * ab0[k];
+        r3[i] = -sw_f * sj;
       }
     };
-    {
-      double blk[12][3], brhs[12];
-      for (int i = 0; i < 6; i++) {
-        for (int j = 0; j < 3; j++) {
-          double s = 0.0;
-          for (int k = 0; k < 6; k++) s += WBC_SH_GET(Lsh[6 * i + k]) * B[k][j];
-          if (!ct) s += st.get(ST_MTBL + 3 * i + j);
-          blk[i][j] = sw_b * s;
-        }
-        double s = c1_b[i];
-        for (int k = 0; k < 6; k++) s += WBC_SH_GET(Lsh[6 * i + k]) * ab0[k];
-        brhs[i] = -sw_b * s;
-      }
-      swing_rows(sw_leg[0], blk + 6, brhs + 6);
-      swing_rows(sw_leg[1], blk + 9, brhs + 9);
-      quad_qr_append<Q, 12>(qo, l, Rc, rhsR, blk, brhs);
-    }
+    swing_rows(sw0, blk + 6, brhs + 6);
+    swing_rows(sw1, blk + 9, brhs + 9);
+    quad_qr_append<Q, 12>(qo, l, Rc, rhsR, blk, brhs);
     if (ns > 2) {
-      double blk[6][3], brhs[6];
-      swing_rows(sw_leg[2], blk, brhs);
-      swing_rows(sw_leg[3], blk + 3, brhs + 3);
-      quad_qr_append<Q, 6>(qo, l, Rc, rhsR, blk, brhs);
+      double blk2[6][3], brhs2[6];
+      swing_rows(sw2, blk2, brhs2);
+      swing_rows(sw3, blk2 + 3, brhs2 + 3);
+      quad_qr_append<Q, 6>(qo, l, Rc, rhsR, blk2, brhs2);
     }
   }
+  WBC_CUT_AT(3, Rc[0][0] + Rc[5][1] + Rc[11][2] + rhsR[0] + rhsR[7] + rhsR[11] + met_V + met_Vdot + vrow[1] + vconst + B[2][2] + ab0[1] + t0l[1])
   WBC_STAMP(9);
   // ---------------- level-2 rows eps (T z + t0): own COLUMNS of the torque map, built here
   //   T[3l'+i][3l+j] = (Y_l' B_l)[i][j] + delta_{l l'} D_l[i][j] ;  t0 replicated
   {
     double blk[12][3], brhs[12];
+    double B2[6][3], ab2[6];
+    for (int i = 0; i < 6; i++) {
+      ab2[i] = st.get(ST_AB0 + i);
+      for (int j = 0; j < 3; j++) B2[i][j] = st.get(ST_B + 3 * i + j);
+    }
     double Y[18], Dl[9];  // Dl = own diagonal block D_l: -Jl' (contact) or Pm (swing)
     for (int i = 0; i < 18; i++) Y[i] = st.get(ST_Y + i);
     for (int i = 0; i < 3; i++)
@@ -755,13 +816,13 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
       for (int i = 0; i < 3; i++) {
         double t0r = qo.bcast_s(t0l[i], lp);
 #pragma unroll
-        for (int k = 0; k < 6; k++) t0r += Yp[6 * i + k] * ab0[k];
+        for (int k = 0; k < 6; k++) t0r += Yp[6 * i + k] * ab2[k];
         brhs[3 * lp + i] = -eps * t0r;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
           double s = 0.0;
 #pragma unroll
-          for (int k = 0; k < 6; k++) s += Yp[6 * i + k] * B[k][j];
+          for (int k = 0; k < 6; k++) s += Yp[6 * i + k] * B2[k][j];
           if (lp == l) s += Dl[3 * i + j];
           blk[3 * lp + i][j] = eps * s;
         }
@@ -769,6 +830,7 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
     }
     quad_qr_append<Q, 12>(qo, l, Rc, rhsR, blk, brhs);
   }
+  WBC_CUT_AT(4, Rc[0][0] + Rc[5][1] + Rc[11][2] + Rc[3][0] + rhsR[0] + rhsR[7] + rhsR[11] + met_V + met_Vdot + vrow[1] + vconst + B[2][2] + ab0[1] + t0l[1])
   WBC_STAMP(10);
   // ---------------- gather R, unconstrained minimiser, own rows of J = R^-1
   double zl[3], Jr[3][NZ];
@@ -822,6 +884,7 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
       }
     }
   }
+  WBC_CUT_AT(5, zl[0] + zl[1] + zl[2] + Jr[0][0] + Jr[1][5] + Jr[2][11] + Jr[0][7] + met_V + met_Vdot + vrow[1] + vconst + B[2][2] + ab0[1] + t0l[1])
   WBC_STAMP(11);
   // ---------------- friction rows
   int iters = 0;
@@ -831,11 +894,13 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
     if (st != ST_OK) status = st;
   }
   *iters_out = iters;
+  WBC_CUT_AT(6, zl[0] + zl[1] + zl[2] + (double)iters + met_V + met_Vdot + vrow[1] + vconst + B[2][2] + ab0[1] + t0l[1])
   WBC_STAMP(12);
   // ---------------- outputs: a_b = ab0 + sum_l B_l z_l ;  tau_l = Y_l a_b + D_l z_l + t0l
   {
     double ab[6];
-    for (int i = 0; i < 6; i++) ab[i] = ab0[i] + qo.sum(B[i][0] * zl[0] + B[i][1] * zl[1] + B[i][2] * zl[2]);
+    for (int i = 0; i < 6; i++)
+      ab[i] = st.get(ST_AB0 + i) + qo.sum(st.get(ST_B + 3 * i) * zl[0] + st.get(ST_B + 3 * i + 1) * zl[1] + st.get(ST_B + 3 * i + 2) * zl[2]);
     for (int i = 0; i < 3; i++) {
       double s = t0l[i];
       for (int k = 0; k < 6; k++) s += st.get(ST_Y + 6 * i + k) * ab[k];

@@ -206,8 +206,10 @@ WBC_HD void leg_fk(const ModelC& m, int l, const T* R0, const T* sn, const T* cs
 // Newton-Euler bias pass for one leg (vd = 0): joint torques hl and the leg's reaction wrench
 // (Nb about the base origin, Fb).  w0 = base angular velocity, qd = own joint rates, gz = gravity.
 // Optionally also returns the foot bias acceleration / velocities / Jd columns.
+// mass3 = the three link masses of this leg, loaded ONCE by the caller: a per-lane indexed model
+// load inside every pass is a full global-memory round trip at one wavefront per SIMD.
 template <class T, bool KINEXTRA, class KinT>
-WBC_HD void leg_rnea(const ModelC& m, int l, const KinT& K, const T* w0, const T* qd, T gz, T* hl, T* Nb,
+WBC_HD void leg_rnea(const T* mass3, const KinT& K, const T* w0, const T* qd, T gz, T* hl, T* Nb,
                      T* Fb, LegDyn<T>* D) {
   T w[3] = {w0[0], w0[1], w0[2]};
   T al[3] = {T(0.0), T(0.0), T(0.0)};
@@ -249,7 +251,7 @@ WBC_HD void leg_rnea(const ModelC& m, int l, const KinT& K, const T* w0, const T
     symv(Iw, w, Iw_w);
     symv(Iw, al, Ial);
     cross(w, Iw_w, t3);
-    T mk = T(m.link[l][k].mass), t4[3];
+    T mk = mass3[k], t4[3];
     cross(mcw, ag, t4);
     for (int i = 0; i < 3; i++) {
       F[k][i] = mk * ag[i] + t1[i] + t2[i];
@@ -288,7 +290,7 @@ WBC_HD void leg_rnea(const ModelC& m, int l, const KinT& K, const T* w0, const T
 
 // Composite-rigid-body pass for one leg: Mbl, Mll and the leg's composite inertia at the base origin.
 template <class T, class KinT>
-WBC_HD void leg_crba(const ModelC& m, int l, const KinT& K, LegDyn<T>& D, T& Mc, T* Hc, T* Ic) {
+WBC_HD void leg_crba(const T* mass3, const KinT& K, LegDyn<T>& D, T& Mc, T* Hc, T* Ic) {
   T cm = T(0.0), ch[3] = {T(0.0), T(0.0), T(0.0)}, cI[6] = {T(0.0), T(0.0), T(0.0), T(0.0), T(0.0), T(0.0)};
   T rk[3][3], axk[3][3];
   for (int k = 0; k < 3; k++)
@@ -301,7 +303,7 @@ WBC_HD void leg_crba(const ModelC& m, int l, const KinT& K, LegDyn<T>& D, T& Mc,
       T r[3] = {rk[k + 1][0] - rk[k][0], rk[k + 1][1] - rk[k][1], rk[k + 1][2] - rk[k][2]};
       shift_add(cm, ch, cI, r, nm, nh, nI);
     }
-    T mk = T(m.link[l][k].mass);
+    T mk = mass3[k];
     T mcw[3] = {K.mcw(k, 0), K.mcw(k, 1), K.mcw(k, 2)};
     T Iw[6] = {K.Iw(k, 0), K.Iw(k, 1), K.Iw(k, 2), K.Iw(k, 3), K.Iw(k, 4), K.Iw(k, 5)};
     shift_add(mk, mcw, Iw, zero, nm, nh, nI);
@@ -618,9 +620,10 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     }
     leg_fk(m, l, R0, sn, cs, K[l]);
     T Nb[3], Fb[3];
-    leg_rnea<T, true>(m, l, K[l], w0, qd[l], gz, D[l].hl, Nb, Fb, &D[l]);
+    const T mass3[3] = {T(m.link[l][0].mass), T(m.link[l][1].mass), T(m.link[l][2].mass)};
+    leg_rnea<T, true>(mass3, K[l], w0, qd[l], gz, D[l].hl, Nb, Fb, &D[l]);
     for (int i = 0; i < 3; i++) { hb[i] = hb[i] + Nb[i]; hb[3 + i] = hb[3 + i] + Fb[i]; }
-    leg_crba(m, l, K[l], D[l], Mc, Hc, Ic);
+    leg_crba(mass3, K[l], D[l], Mc, Hc, Ic);
     // foot Jacobian block wrt own joints
     for (int k = 0; k < 3; k++) {
       T d[3] = {K[l].rf(0) - K[l].r(k, 0), K[l].rf(1) - K[l].r(k, 1), K[l].rf(2) - K[l].r(k, 2)}, c[3];
@@ -889,7 +892,8 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       for (int l = 0; l < 4; l++) {
         T qv[3] = {qd[l][0] + sg * xi_l[l][0], qd[l][1] + sg * xi_l[l][1], qd[l][2] + sg * xi_l[l][2]};
         T hl2[3], Nb[3], Fb[3];
-        leg_rnea<T, false>(m, l, K[l], wv, qv, T(0.0), hl2, Nb, Fb, (LegDyn<T>*)nullptr);
+        const T mass3[3] = {T(m.link[l][0].mass), T(m.link[l][1].mass), T(m.link[l][2].mass)};
+        leg_rnea<T, false>(mass3, K[l], wv, qv, T(0.0), hl2, Nb, Fb, (LegDyn<T>*)nullptr);
         for (int i = 0; i < 3; i++) {
           Cxi_b[i] = Cxi_b[i] + sg * T(0.25) * Nb[i];
           Cxi_b[3 + i] = Cxi_b[3 + i] + sg * T(0.25) * Fb[i];

@@ -138,6 +138,8 @@ struct QuadHost {
     c->bar.arrive_and_wait();
     return r;
   }
+  bool wave_all(bool b) { return b; }
+  int wave_max_int(int x) { return x; }  // one quad per "wave" in the emulation; b is replicated
   bool any(bool b) {
     c->islot[l] = b; c->bar.arrive_and_wait();
     bool r = c->islot[0] | c->islot[1] | c->islot[2] | c->islot[3];
