@@ -8,6 +8,7 @@
  *         controllers/basic_controller.py:286-320
  *         controllers/inverse_dynamics_controller.py:103-234   (kind = WBC_KIND_ID)
  *         controllers/mptc_controller.py:125-310               (kind = WBC_KIND_MPTC)
+ *         controllers/pc_controller.py:44-255                  (kind = WBC_KIND_PC)
  *
  * i.e. everything between the reference's `quad_state` / `trunk_input` input ports and its
  * `quad_torques` / `output_metrics` output ports (basic_controller.py:33-50,
@@ -42,6 +43,7 @@ extern "C" {
 
 #define WBC_KIND_ID 0
 #define WBC_KIND_MPTC 1
+#define WBC_KIND_PC 2 /* controllers/pc_controller.py:44-255: MPTC + passivity row Vdot <= 0 */
 
 #define WBC_MODEL_FLAT 215
 #define WBC_NQ 19

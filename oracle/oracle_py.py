@@ -36,11 +36,11 @@ class OrcParams(C.Structure):
 
 class OrcQP(C.Structure):
     _fields_ = [("n", C.c_int), ("nc", C.c_int), ("me", C.c_int), ("mi", C.c_int), ("mls", C.c_int),
-                ("Q", C.c_double * (42 * 42)), ("c", C.c_double * 42),
-                ("Aeq", C.c_double * (30 * 42)), ("beq", C.c_double * 30),
-                ("Ain", C.c_double * (40 * 42)), ("bin", C.c_double * 40),
-                ("Als", C.c_double * (18 * 42)), ("bls", C.c_double * 18),
-                ("x", C.c_double * 42), ("iters", C.c_int), ("status", C.c_int),
+                ("Q", C.c_double * (43 * 43)), ("c", C.c_double * 43),
+                ("Aeq", C.c_double * (30 * 43)), ("beq", C.c_double * 30),
+                ("Ain", C.c_double * (42 * 43)), ("bin", C.c_double * 42),
+                ("Als", C.c_double * (18 * 43)), ("bls", C.c_double * 18),
+                ("x", C.c_double * 43), ("iters", C.c_int), ("status", C.c_int),
                 ("primal_res", C.c_double)]
 
 
@@ -59,6 +59,7 @@ def lib():
         _LIB.orc_qp_solve.restype = C.c_int
         _LIB.orc_id_control_law.restype = C.c_int
         _LIB.orc_mptc_control_law.restype = C.c_int
+        _LIB.orc_pc_control_law.restype = C.c_int
         _LIB.orc_step_batch.restype = C.c_int
     return _LIB
 
@@ -82,6 +83,10 @@ def model(name_or_table):
     for i, a in enumerate(t.get("act_perm", range(12))):
         m.act_perm[i] = a
     return m
+
+
+def kind_index(kind):
+    return 0 if kind in (0, "id", "ID") else (2 if kind in (2, "pc", "PC") else 1)
 
 
 def params(kind):
@@ -149,7 +154,8 @@ def control_law(kind, m, p, q, v, targets, contact, want_qp=False):
     ct = (C.c_int * 4)(*[int(bool(c)) for c in contact])
     tau = np.zeros(12); met = np.zeros(4)
     qp = OrcQP() if want_qp else None
-    fn = lib().orc_id_control_law if kind in (0, "id", "ID") else lib().orc_mptc_control_law
+    fn = (lib().orc_id_control_law if kind in (0, "id", "ID") else
+          lib().orc_pc_control_law if kind in (2, "pc", "PC") else lib().orc_mptc_control_law)
     st = fn(C.byref(m), C.byref(p), _p(q), _p(v), _p(targets), ct, _p(tau), _p(met),
             C.byref(qp) if want_qp else None)
     if not want_qp:
@@ -185,7 +191,7 @@ def step_batch(kind, m, p, q, v, targets, mask, mu=None, mass_scale=None, nthrea
     ms_a = np.ascontiguousarray(mass_scale, dtype=np.float64) if mass_scale is not None else None
     mu_p = _p(mu_a) if mu_a is not None else None
     ms_p = _p(ms_a) if ms_a is not None else None
-    kind_i = 0 if kind in (0, "id", "ID") else 1
+    kind_i = kind_index(kind)
     lib().orc_step_batch(C.byref(m), C.byref(p), kind_i, n, n, _p(q), _p(v), _p(targets),
                          mask.ctypes.data_as(C.POINTER(C.c_ubyte)), mu_p, ms_p, _p(tau), _p(met),
                          st.ctypes.data_as(c_int_p), int(nthreads))
@@ -200,7 +206,7 @@ def bench_batch(kind, m, p, q, v, targets, mask, mu=None, mass_scale=None, nthre
     tau = np.zeros((12, n)); st = np.zeros(n, dtype=np.int32)
     mu_a = np.ascontiguousarray(mu, dtype=np.float64) if mu is not None else None
     ms_a = np.ascontiguousarray(mass_scale, dtype=np.float64) if mass_scale is not None else None
-    kind_i = 0 if kind in (0, "id", "ID") else 1
+    kind_i = kind_index(kind)
     lib().orc_bench_batch(C.byref(m), C.byref(p), kind_i, n, n, _p(q), _p(v), _p(targets),
                           mask.ctypes.data_as(C.POINTER(C.c_ubyte)), _p(mu_a) if mu_a is not None else None,
                           _p(ms_a) if ms_a is not None else None, _p(tau), st.ctypes.data_as(c_int_p),

@@ -384,7 +384,7 @@ static void rpy_Einv(const double* rpy, double* Ei) {
 /* Householder QR of A (m x n, m >= n), in place: R in the upper triangle; Q (m x m) explicit. */
 static void householder_qr(int m, int n, double* A, double* Q) {
   for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Q[i * m + j] = (i == j);
-  double w[64]; /* m <= 60 here */
+  double w[64]; /* m <= 62 here */
   for (int k = 0; k < n && k < m - 1; k++) {
     double nrm = 0;
     for (int i = k; i < m; i++) nrm += A[i * n + k] * A[i * n + k];
@@ -528,8 +528,8 @@ int orc_qp_solve(int n, int mls, const double* Als, const double* bls, double ep
   int nz = n - me, status = 0;
   *iters = 0;
   /* fixed workspaces (n <= 42, me <= 30, reduced rows <= 60): the hot loop never touches the heap */
-  double At[42 * 30], Q[42 * 42], xp[42];
-  if (n > 42 || me > 30) return 2;
+  double At[ORC_NMAX * 30], Q[ORC_NMAX * ORC_NMAX], xp[ORC_NMAX];
+  if (n > ORC_NMAX || me > 30) return 2;
   memset(xp, 0, sizeof xp);
   /* 1. null-space basis of the equalities: Aeq' = Q [R1; 0] */
   for (int i = 0; i < me; i++) for (int j = 0; j < n; j++) At[j * me + i] = Aeq[i * n + j];
@@ -558,8 +558,8 @@ int orc_qp_solve(int n, int mls, const double* Als, const double* bls, double ep
     for (int i = 0; i < n; i++) if (dreg[i] > 0) nreg++;
     int mB = mls + nreg;
     if (mB < nz) { status = 2; goto done; }
-    double B[60 * GI_MAXN], rhs[60], QB[60 * 60];
-    if (mB > 60) { status = 2; goto done; }
+    double B[62 * GI_MAXN], rhs[62], QB[62 * 62];
+    if (mB > 62) { status = 2; goto done; }
     memset(B, 0, sizeof B); memset(rhs, 0, sizeof rhs);
     for (int i = 0; i < mls; i++) {
       double s = bls[i];
@@ -686,8 +686,8 @@ static void tick_head(const orc_model* m, const double* q, const double* v, cons
 
 /* Constraint builders shared verbatim by both laws (inverse_dynamics_controller.py:48-101 ==
  * mptc_controller.py:70-123).  x = [vd(18); tau(12); f_1..f_nc]. */
-static void build_constraints(const tick_common* T, const orc_params* p, const double* v, orc_qp* qp) {
-  int nc = T->nc, n = 30 + 3 * nc;
+static void build_constraints(const tick_common* T, const orc_params* p, const double* v, orc_qp* qp, int n) {
+  int nc = T->nc;
   qp->n = n; qp->nc = nc;
   memset(qp->Aeq, 0, sizeof qp->Aeq); memset(qp->beq, 0, sizeof qp->beq);
   memset(qp->Ain, 0, sizeof qp->Ain); memset(qp->bin, 0, sizeof qp->bin);
@@ -731,8 +731,8 @@ static void build_constraints(const tick_common* T, const orc_params* p, const d
 }
 
 static int solve_and_extract(const orc_params* p, orc_qp* qp, double* tau) {
-  double dreg[42];
-  for (int i = 0; i < qp->n; i++) dreg[i] = (i >= 18) ? 1.0 : 0.0; /* tie-break on [tau; f] */
+  double dreg[ORC_NMAX];
+  for (int i = 0; i < qp->n; i++) dreg[i] = (i >= 18) ? 1.0 : 0.0; /* tie-break on [tau; f] (and delta) */
   qp->status = orc_qp_solve(qp->n, qp->mls, qp->Als, qp->bls, p->tiebreak_eps2, dreg, qp->me, qp->Aeq,
                             qp->beq, qp->mi, qp->Ain, qp->bin, qp->x, &qp->iters, &qp->primal_res);
   for (int k = 0; k < 12; k++) tau[k] = (qp->status == 2) ? 0.0 : qp->x[18 + k];
@@ -790,7 +790,7 @@ int orc_id_control_law(const orc_model* m, const orc_params* p, const double* q,
     }
   }
   qp->mls = row;
-  build_constraints(T, p, v, qp); /* :213-221 */
+  build_constraints(T, p, v, qp, n); /* :213-221 */
   int status = solve_and_extract(p, qp, tau); /* :223-225 */
   /* :227-232 logging */
   double err = 0;
@@ -807,14 +807,14 @@ int orc_id_control_law(const orc_model* m, const orc_params* p, const double* q,
   return status;
 }
 
-/* mptc_controller.py:125-310 */
-int orc_mptc_control_law(const orc_model* m, const orc_params* p, const double* q, const double* v,
-                         const double* targets, const int* contact, double* tau, double* metrics,
-                         orc_qp* qp_out) {
+/* mptc_controller.py:125-310; with pc != 0 additionally pc_controller.py:14-40,202,229-237 */
+static int mptc_like_control_law(const orc_model* m, const orc_params* p, const double* q, const double* v,
+                                 const double* targets, const int* contact, double* tau, double* metrics,
+                                 orc_qp* qp_out, int pc) {
   tick_common Ts, *T = &Ts;
   orc_qp qps, *qp = qp_out ? qp_out : &qps;
   tick_head(m, q, v, targets, contact, T);
-  int nc = T->nc, ns = T->ns, n = 30 + 3 * nc, mt = 6 + 3 * ns, nf = 3 * ns;
+  int nc = T->nc, ns = T->ns, n = 30 + 3 * nc + (pc ? 1 : 0), mt = 6 + 3 * ns, nf = 3 * ns;
   double C[18 * 18];
   orc_coriolis_matrix(m, q, v, C); /* :158 */
   /* :227-235 stacked task Jacobian J (mt x 18), Jd */
@@ -895,10 +895,32 @@ int orc_mptc_control_law(const orc_model* m, const orc_params* p, const double* 
     qp->bls[a] = sw * f_des[a];
   }
   qp->mls = mt;
-  build_constraints(T, p, v, qp); /* :284-292 */
+  build_constraints(T, p, v, qp, n); /* :284-292 */
+  if (pc) {
+    /* pc_controller.py:14-40 AddVdotConstraint: xd_tilde' Jbar' U [tau; f] - delta <= ub ;  :233-237 delta <= 0 */
+    double a18[18], b18[18], c18[18], d18[18], ub = 0;
+    int r = qp->mi;
+    for (int j = 0; j < nu; j++) {
+      double sj = 0;
+      for (int a = 0; a < mt; a++) sj += xdt[a] * G[a * nu + j];
+      qp->Ain[r * n + 18 + j] = sj;
+    }
+    qp->Ain[r * n + n - 1] = -1.0;
+    mtv(18, mt, Jbar, T->tau_g, a18);          /* Jbar' tau_g */
+    mv(18, mt, Jbar, xdt, b18);                /* Jbar xd_tilde - v */
+    for (int i = 0; i < 18; i++) b18[i] -= v[i];
+    mv(mt, 18, Qm, b18, c18);
+    mv(mt, mt, Lam, c18, d18);                 /* Lam Q (Jbar xd_tilde - v) */
+    mv(mt, mt, Lam, xdd_nom, c18);             /* Lam xdd_nom */
+    for (int a = 0; a < mt; a++) ub += xdt[a] * (a18[a] - d18[a] + c18[a] - Kp[a] * xt[a]);
+    qp->bin[r] = ub;
+    qp->Ain[(r + 1) * n + n - 1] = 1.0;
+    qp->bin[r + 1] = 0.0;
+    qp->mi += 2;
+  }
   int status = bad ? 2 : solve_and_extract(p, qp, tau); /* :294-296 */
   if (bad) { for (int k = 0; k < 12; k++) tau[k] = 0; qp->status = 2; }
-  /* :298-308 logging */
+  /* :298-308 logging (pc_controller.py:240-252 is identical) */
   if (metrics) {
     double V = 0, err = 0, Vdot = 0;
     mv(mt, mt, Lam, xdt, a18);
@@ -918,6 +940,17 @@ int orc_mptc_control_law(const orc_model* m, const orc_params* p, const double* 
   }
   (void)tmp;
   return status;
+}
+
+int orc_mptc_control_law(const orc_model* m, const orc_params* p, const double* q, const double* v,
+                         const double* targets, const int* contact, double* tau, double* metrics,
+                         orc_qp* qp_out) {
+  return mptc_like_control_law(m, p, q, v, targets, contact, tau, metrics, qp_out, 0);
+}
+int orc_pc_control_law(const orc_model* m, const orc_params* p, const double* q, const double* v,
+                       const double* targets, const int* contact, double* tau, double* metrics,
+                       orc_qp* qp_out) {
+  return mptc_like_control_law(m, p, q, v, targets, contact, tau, metrics, qp_out, 1);
 }
 
 /* ------------------------------------------------------------------ batched driver */
@@ -945,7 +978,8 @@ int orc_step_batch(const orc_model* m, const orc_params* p, int kind, int n, int
       for (int k = 0; k < 6; k++) ml.base_I[k] *= mass_scale[i];
     }
     int st = (kind == 0) ? orc_id_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
-                         : orc_mptc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL);
+             : (kind == 1) ? orc_mptc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
+                           : orc_pc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL);
     for (int k = 0; k < 12; k++) tau[(size_t)k * stride + i] = ti[k];
     if (metrics) for (int k = 0; k < 4; k++) metrics[(size_t)k * stride + i] = mi[k];
     if (status) status[i] = st;
@@ -981,7 +1015,8 @@ int orc_bench_batch(const orc_model* m, const orc_params* p, int kind, int n, in
       for (int k = 0; k < 6; k++) ml.base_I[k] *= mass_scale[i];
     }
     int st = (kind == 0) ? orc_id_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
-                         : orc_mptc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL);
+             : (kind == 1) ? orc_mptc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
+                           : orc_pc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL);
     if (j >= total - n) {
       for (int k = 0; k < 12; k++) tau[(size_t)k * stride + i] = ti[k];
       if (status) status[i] = st;

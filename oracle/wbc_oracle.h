@@ -82,13 +82,15 @@ void orc_rpy_from_R(const double* R, double* rpy);
 void orc_rpy_E(const double* rpy, double* E /*3x3: omega = E rpyDt*/);
 
 /* Literal QP data of one tick (n = 30 + 3 nc).  Filled by the control laws for inspection. */
+#define ORC_NMAX 43 /* 18 + 12 + 12 (+ 1 slack delta of the PC law) */
+#define ORC_MIN 42  /* 16 friction + 24 torque box + 2 PC rows */
 typedef struct {
   int n, nc, me, mi, mls;
-  double Q[42 * 42], c[42];           /* 1/2 x'Qx + c'x, exactly as the reference adds them */
-  double Aeq[30 * 42], beq[30];       /* dynamics rows then contact rows */
-  double Ain[(16 + 24) * 42], bin[16 + 24]; /* Ain x <= bin: friction rows (+ optional torque box) */
-  double Als[18 * 42], bls[18];       /* square-root form of the cost: 1/2|Als x - bls|^2 = cost + const */
-  double x[42];                       /* solution */
+  double Q[ORC_NMAX * ORC_NMAX], c[ORC_NMAX]; /* 1/2 x'Qx + c'x, exactly as the reference adds them */
+  double Aeq[30 * ORC_NMAX], beq[30];         /* dynamics rows then contact rows */
+  double Ain[ORC_MIN * ORC_NMAX], bin[ORC_MIN]; /* Ain x <= bin: friction (+ PC rows, + optional torque box) */
+  double Als[18 * ORC_NMAX], bls[18];         /* square-root form of the cost: 1/2|Als x - bls|^2 = cost + const */
+  double x[ORC_NMAX];                         /* solution */
   int iters, status;
   double primal_res;
 } orc_qp;
@@ -103,6 +105,11 @@ int orc_id_control_law(const orc_model* m, const orc_params* p, const double* q,
 int orc_mptc_control_law(const orc_model* m, const orc_params* p, const double* q, const double* v,
                          const double* targets, const int* contact, double* tau, double* metrics,
                          orc_qp* qp_out /* nullable */);
+/* controllers/pc_controller.py:44-255: MPTC + slack delta, rows Vdot <= delta and delta <= 0
+ * (x = [vd; tau; f; delta], n = 31 + 3 nc).  delta carries no cost in the reference (:207-217). */
+int orc_pc_control_law(const orc_model* m, const orc_params* p, const double* q, const double* v,
+                       const double* targets, const int* contact, double* tau, double* metrics,
+                       orc_qp* qp_out /* nullable */);
 
 /* Generic dense QP used by both laws:
  *   min 1/2|Als x - bls|^2 + 1/2 eps2 sum_i dreg[i] x_i^2   s.t. Aeq x = beq, Ain x <= bin
@@ -113,7 +120,7 @@ int orc_qp_solve(int n, int mls, const double* Als, const double* bls, double ep
                  const double* bin, double* x, int* iters, double* primal_res);
 
 /* Batched driver over SoA arrays (batch index fastest), OpenMP over instances when built
- * with -fopenmp.  kind: 0 = ID, 1 = MPTC.  mask bit i = foot i in contact.
+ * with -fopenmp.  kind: 0 = ID, 1 = MPTC, 2 = PC.  mask bit i = foot i in contact.
  * mu / mass_scale may be NULL.  Used by tests and by bench.py's cpu_baseline leg. */
 int orc_step_batch(const orc_model* m, const orc_params* p, int kind, int n, int stride, const double* q,
                    const double* v, const double* targets, const unsigned char* mask, const double* mu,

@@ -213,6 +213,11 @@ class MPTCController(BatchedController):
     kind = _lib.KIND_MPTC
 
 
+class PCController(BatchedController):
+    """controllers/pc_controller.py:3-255 (MPTC + passivity constraint Vdot <= 0), batched."""
+    kind = _lib.KIND_PC
+
+
 def make_leaf_system(plant, dt, control_method="ID", model="mini_cheetah", use_lcm=False, **kw):
     """Drop-in for `IDController(plant, dt, use_lcm)` / `MPTCController(...)` in simulate.py:106-118:
     a pydrake LeafSystem with the reference's four ports (basic_controller.py:33-50,
@@ -229,7 +234,7 @@ def make_leaf_system(plant, dt, control_method="ID", model="mini_cheetah", use_l
     q_perm = [plant.GetJointByName(nm).velocity_start() - 6 for nm in joint_names]
     B = plant.MakeActuationMatrix()  # nv x nu
     act_perm = [q_perm.index(int(np.argmax(B[6:, k]))) for k in range(12)]
-    cls = IDController if control_method == "ID" else MPTCController
+    cls = {"ID": IDController, "MPTC": MPTCController, "PC": PCController}[control_method]
     ctrl = cls(model=table, max_batch=1, host_ptrs=True, q_perm=q_perm, act_perm=act_perm, **kw)
 
     class _Leaf(LeafSystem):

@@ -360,7 +360,7 @@ const char* wbc_last_error(void) { return g_err; }
 int wbc_version(void) { return 100; }
 
 int wbc_params_default(int kind, wbc_params* out) {
-  if (!out || (kind != WBC_KIND_ID && kind != WBC_KIND_MPTC)) return misuse("wbc_params_default: bad argument");
+  if (!out || kind < WBC_KIND_ID || kind > WBC_KIND_PC) return misuse("wbc_params_default: bad argument");
   static_assert(sizeof(wbc_params) == sizeof(wbc::ParamsC), "params layout");
   wbc::params_default(kind, reinterpret_cast<wbc::ParamsC*>(out));
   return 0;
@@ -369,7 +369,7 @@ int wbc_params_default(int kind, wbc_params* out) {
 int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int max_batch, int device,
                uint32_t flags, wbc_handle* out) {
   if (!model || !out) return misuse("wbc_create: null argument");
-  if (kind != WBC_KIND_ID && kind != WBC_KIND_MPTC) return misuse("wbc_create: kind must be WBC_KIND_ID or WBC_KIND_MPTC");
+  if (kind < WBC_KIND_ID || kind > WBC_KIND_PC) return misuse("wbc_create: kind must be WBC_KIND_ID, WBC_KIND_MPTC or WBC_KIND_PC");
   if (max_batch <= 0) return misuse("wbc_create: max_batch must be positive");
   wbc::ModelC m;
   if (wbc::model_from_flat(model->flat, &m)) return misuse("wbc_create: joint axes must be axis-aligned");
@@ -457,23 +457,30 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
   const bool quad = (h->variant == 2) || (h->variant == 0 && !h->torque_box);
   dim3 block(BLOCK);
   StatsDev* d_stats = getenv("WBC_NO_STATS") ? nullptr : h->d_stats;  // diagnostic switch
+#define WBC_LAUNCH(KERNEL, GRID)                                                                              \
+  do {                                                                                                       \
+    switch (h->kind) {                                                                                       \
+      case WBC_KIND_ID:                                                                                      \
+        hipLaunchKernelGGL(KERNEL<wbc::KIND_ID>, GRID, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg, \
+                           mask, mu, ms, tau, met, status, d_stats);                                         \
+        break;                                                                                               \
+      case WBC_KIND_MPTC:                                                                                    \
+        hipLaunchKernelGGL(KERNEL<wbc::KIND_MPTC>, GRID, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v,   \
+                           tg, mask, mu, ms, tau, met, status, d_stats);                                     \
+        break;                                                                                               \
+      default:                                                                                               \
+        hipLaunchKernelGGL(KERNEL<wbc::KIND_PC>, GRID, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg, \
+                           mask, mu, ms, tau, met, status, d_stats);                                         \
+    }                                                                                                        \
+  } while (0)
   if (quad) {
     dim3 grid((n + QROBOTS - 1) / QROBOTS);
-    if (h->kind == WBC_KIND_ID)
-      hipLaunchKernelGGL(wbc_quad_kernel<wbc::KIND_ID>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q,
-                         v, tg, mask, mu, ms, tau, met, status, d_stats);
-    else
-      hipLaunchKernelGGL(wbc_quad_kernel<wbc::KIND_MPTC>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld,
-                         q, v, tg, mask, mu, ms, tau, met, status, d_stats);
+    WBC_LAUNCH(wbc_quad_kernel, grid);
   } else {
     dim3 grid((n + BLOCK - 1) / BLOCK);
-    if (h->kind == WBC_KIND_ID)
-      hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_ID>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q,
-                         v, tg, mask, mu, ms, tau, met, status, d_stats);
-    else
-      hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_MPTC>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld,
-                         q, v, tg, mask, mu, ms, tau, met, status, d_stats);
+    WBC_LAUNCH(wbc_tick_kernel, grid);
   }
+#undef WBC_LAUNCH
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -584,11 +591,12 @@ int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_by
   if (!h) return misuse("wbc_kernel_info: null handle");
   hipFuncAttributes a;
   const bool quad = (h->variant == 2) || (h->variant == 0 && !h->torque_box);
-  if (quad) {
-    if (h->kind == WBC_KIND_ID) HIP_TRY(hipFuncGetAttributes(&a, (const void*)wbc_quad_kernel<wbc::KIND_ID>));
-    else HIP_TRY(hipFuncGetAttributes(&a, (const void*)wbc_quad_kernel<wbc::KIND_MPTC>));
-  } else if (h->kind == WBC_KIND_ID) HIP_TRY(hipFuncGetAttributes(&a, (const void*)wbc_tick_kernel<wbc::KIND_ID>));
-  else HIP_TRY(hipFuncGetAttributes(&a, (const void*)wbc_tick_kernel<wbc::KIND_MPTC>));
+  const void* fn;
+  if (quad) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_quad_kernel<wbc::KIND_ID>
+               : h->kind == WBC_KIND_MPTC ? (const void*)wbc_quad_kernel<wbc::KIND_MPTC> : (const void*)wbc_quad_kernel<wbc::KIND_PC>;
+  else fn = h->kind == WBC_KIND_ID ? (const void*)wbc_tick_kernel<wbc::KIND_ID>
+          : h->kind == WBC_KIND_MPTC ? (const void*)wbc_tick_kernel<wbc::KIND_MPTC> : (const void*)wbc_tick_kernel<wbc::KIND_PC>;
+  HIP_TRY(hipFuncGetAttributes(&a, fn));
   if (num_vgpr) *num_vgpr = a.numRegs;
   if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;
   if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;

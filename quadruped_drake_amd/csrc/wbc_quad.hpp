@@ -107,9 +107,12 @@ WBC_HD void gi_dual(const QuadShared& sh, int q, const double* d, double* r, int
 // primal/dual step ending in an add or a drop).  The textbook nested loops make the 16 robots of a
 // wavefront diverge into different loop bodies and serialise (measured 6 us per step); here the
 // trip count is the maximum over the robots, not the sum.
+// Optional PC row (pc_controller.py): Vdot(z) = sum_l vrow_l . z_l + vc <= 0, index 16; every lane
+// holds its own three coefficients, normalised by pc_inv = 1/|vrow| (0 disables the row).
 template <class Q>
 WBC_HD int quad_gi(Q& qo, int l, bool ct, double (*Jr)[NZ], double* zl, double mu_n, double inv_s, QuadShared& sh,
-                   int* iters_out) {
+                   int* iters_out, const double* vrow_l = nullptr, double vc = 0.0, double pc_inv = 0.0) {
+  const bool pc = pc_inv > 0.0;
   int q = 0, iters = 0, status = ST_OK;
   unsigned active = 0u;
   const int maxit = 200;
@@ -134,15 +137,23 @@ WBC_HD int quad_gi(Q& qo, int l, bool ct, double (*Jr)[NZ], double* zl, double m
         }
       }
       qo.argmin(sp, p);
+      if (pc && !((active >> 16) & 1u)) {
+        const double s = -(qo.sum(vrow_l[0] * zl[0] + vrow_l[1] * zl[1] + vrow_l[2] * zl[2]) + vc) * pc_inv;
+        if (s < sp) { sp = s; p = 16; }
+      }
       if (p < 0) {
         done = true;
       } else {
-        const int owner = p >> 2, rr = p & 3;
-        const double sg = (rr & 1) ? inv_s : -inv_s;
-        const bool mine = (l == owner);
-        npl[0] = (mine && !(rr >> 1)) ? sg : 0.0;
-        npl[1] = (mine && (rr >> 1)) ? sg : 0.0;
-        npl[2] = mine ? mu_n : 0.0;
+        if (p == 16) {
+          npl[0] = -vrow_l[0] * pc_inv; npl[1] = -vrow_l[1] * pc_inv; npl[2] = -vrow_l[2] * pc_inv;
+        } else {
+          const int owner = p >> 2, rr = p & 3;
+          const double sg = (rr & 1) ? inv_s : -inv_s;
+          const bool mine = (l == owner);
+          npl[0] = (mine && !(rr >> 1)) ? sg : 0.0;
+          npl[1] = (mine && (rr >> 1)) ? sg : 0.0;
+          npl[2] = mine ? mu_n : 0.0;
+        }
         sh.u[q] = 0.0;
         need_pick = false;
       }
@@ -251,7 +262,7 @@ WBC_HD int quad_gi(Q& qo, int l, bool ct, double (*Jr)[NZ], double* zl, double m
         }
       }
     }
-    if (!dependent) sp = qo.sum(npl[0] * zl[0] + npl[1] * zl[1] + npl[2] * zl[2]);
+    if (!dependent) sp = qo.sum(npl[0] * zl[0] + npl[1] * zl[1] + npl[2] * zl[2]) - ((p == 16) ? vc * pc_inv : 0.0);
   }
   *iters_out = iters;
   if (!done && status == ST_OK) status = ST_ITER;
@@ -467,7 +478,7 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
       xdt_s[i] = ct ? 0.0 : pd[i] - tpd;
       xdd_s[i] = ct ? 0.0 : tpdd;
     }
-    if (KIND == KIND_MPTC) {
+    if (KIND != KIND_ID) {
       // xi = Jbar xd_tilde on the own joints.  Contact leg: xi = -Mll^-1 (Y xdt_b) - Ji Jfb xdt_b
       // with Y xdt_b = Mbl' xdt_b - Pm (Jfb xdt_b), so neither Y nor Mll^-1 Y is needed yet.
       double Mli[9];
@@ -890,7 +901,14 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
   int iters = 0;
   {
     const double s = sqrt(1.0 + mu * mu);
-    const int st = quad_gi(qo, l, ct, Jr, zl, mu / s, 1.0 / s, sh, &iters);
+    int st;
+    if (KIND == KIND_PC) {
+      // pc_controller.py:14-40,229-237: Vdot <= delta <= 0 with a cost-free delta  <=>  Vdot(z) <= 0
+      const double n2 = qo.sum(vrow[0] * vrow[0] + vrow[1] * vrow[1] + vrow[2] * vrow[2]);
+      st = quad_gi(qo, l, ct, Jr, zl, mu / s, 1.0 / s, sh, &iters, vrow, vconst + met_Vdot, (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0);
+    } else {
+      st = quad_gi(qo, l, ct, Jr, zl, mu / s, 1.0 / s, sh, &iters);
+    }
     if (st != ST_OK) status = st;
   }
   *iters_out = iters;
@@ -912,7 +930,7 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
   if (ct) res = fmax(fabs(zl[0]) - mu * zl[2], fabs(zl[1]) - mu * zl[2]);
   res = fmax(0.0, qo.max(res));
   WBC_STAMP(13);
-  if (KIND == KIND_MPTC) {
+  if (KIND != KIND_ID) {
     met_Vdot += vconst + qo.sum(vrow[0] * zl[0] + vrow[1] * zl[1] + vrow[2] * zl[2]);
     out_met(0, met_V); out_met(1, met_err); out_met(2, 0.0); out_met(3, met_Vdot);
   } else {

@@ -67,7 +67,7 @@ WBC_HD void wbc_sincos(double x, double& s, double& c) {
 }
 template <class T> WBC_HD void wbc_sincos(const T& x, T& s, T& c) { s = sin(x); c = cos(x); }
 
-enum { KIND_ID = 0, KIND_MPTC = 1 };
+enum { KIND_ID = 0, KIND_MPTC = 1, KIND_PC = 2 };  // PC = MPTC + the passivity row Vdot <= 0 (pc_controller.py)
 enum { ST_OK = 0, ST_ITER = 1, ST_SINGULAR = 2 };
 
 struct LinkC {
@@ -359,7 +359,7 @@ template <class T> WBC_HD void mm3(const T* A, const T* B, T* C) {
 template <class T> WBC_HD T wabs(const T& x) { return x < T(0.0) ? T(0.0) - x : x; }
 
 // ---------------------------------------------------------------- QR + Goldfarb-Idnani (n = 12)
-enum { NZ = 12, MAXC = 40 };
+enum { NZ = 12, MAXC = 41, PC_ROW = 40 };
 
 // Fold a block of `p` dense rows A[p][13] (12 coefficients + rhs) into the upper-triangular
 // factor R[12][13] by Householder reflections on [R_kk; A_0k..A_pk].
@@ -393,6 +393,8 @@ template <class T> struct QpCons {
   T tau_max;
   T tnorm[12];
   unsigned mask;
+  const T* pcrow;  // PC law: Vdot(z) = pcrow[0..11].z + pcrow[12] <= 0 (nullable)
+  T pc_inv;        // 1 / |pcrow[0..11]|
 };
 
 template <class T> WBC_HD void cons_normal(const QpCons<T>& C, int i, T* n, T& b) {
@@ -405,6 +407,9 @@ template <class T> WBC_HD void cons_normal(const QpCons<T>& C, int i, T* n, T& b
     n[3 * l + comp] = sg;
     n[3 * l + 2] = C.mu_n;
     b = T(0.0);
+  } else if (i == PC_ROW) {
+    for (int k = 0; k < NZ; k++) n[k] = T(0.0) - C.pcrow[k] * C.pc_inv;
+    b = C.pcrow[NZ] * C.pc_inv;
   } else {
     int j = (i - 16) >> 1;
     T sg = ((i - 16) & 1) ? T(1.0) : T(-1.0);   // even: tau_j <= tau_max -> -T_j z >= t0_j - tau_max
@@ -1036,7 +1041,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     }
   }
   T vdot_row[NZ + 1];
-  for (int c = 0; c <= NZ; c++) vdot_row[c] = (KIND == KIND_MPTC) ? blk[0][c] : T(0.0);
+  for (int c = 0; c <= NZ; c++) vdot_row[c] = (KIND != KIND_ID) ? blk[0][c] : T(0.0);
 
   // ---- level-2 rows: eps (Tm z + t0)
   for (int h = 0; h < 2; h++) {
@@ -1084,6 +1089,8 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     C.Trow = Tm;
     C.tau_max = T(P.tau_max);
     C.mask = mask;
+    C.pcrow = nullptr;
+    C.pc_inv = T(0.0);
   }
   unsigned long long elig = 0ull;
   for (int l = 0; l < 4; l++)
@@ -1094,6 +1101,18 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       for (int k = 0; k < NZ; k++) s = s + Tm[j][k] * Tm[j][k];
       C.tnorm[j] = sqrt(s);
       if (s > T(0.0)) elig |= (3ull << (16 + 2 * j));
+    }
+  }
+  T pcrow[NZ + 1];
+  if (KIND == KIND_PC) {
+    // pc_controller.py:14-40,229-237: Vdot <= delta <= 0 with a cost-free delta  <=>  Vdot <= 0
+    T s = T(0.0);
+    for (int c = 0; c < NZ; c++) { pcrow[c] = vdot_row[c]; s = s + vdot_row[c] * vdot_row[c]; }
+    pcrow[NZ] = vdot_row[NZ] + met_Vdot;
+    if (s > T(0.0)) {
+      C.pcrow = pcrow;
+      C.pc_inv = T(1.0) / sqrt(s);
+      elig |= (1ull << PC_ROW);
     }
   }
   int iters = 0;
@@ -1117,7 +1136,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       if (a > res) res = a;
       if (b > res) res = b;
     }
-  if (KIND == KIND_MPTC) {
+  if (KIND != KIND_ID) {
     T s = vdot_row[NZ];
     for (int c = 0; c < NZ; c++) s = s + vdot_row[c] * z[c];
     met_Vdot = met_Vdot + s;

@@ -16,7 +16,7 @@ def rel_err(tau, tau_o):
     return np.abs(tau - tau_o).max(0) / np.maximum(np.abs(tau_o).max(0), 1e-3)
 
 
-@pytest.mark.parametrize("cfg,kind", [(2, "id"), (3, "mptc"), (3, "id"), (2, "mptc"), (4, "mptc"), (5, "mptc")])
+@pytest.mark.parametrize("cfg,kind", [(2, "id"), (3, "mptc"), (3, "id"), (2, "mptc"), (4, "mptc"), (5, "mptc"), (3, "pc"), (2, "pc")])
 def test_host_kernel_math_matches_oracle(cfg, kind):
     b = workloads.make_batch(cfg, n=192)
     t = orc.load_model_json(b["model"])
@@ -71,7 +71,7 @@ def test_permutations():
     assert np.array_equal(tau2, tau[aperm])
 
 
-@pytest.mark.parametrize("cfg,kind,n", [(2, "id", 24), (3, "mptc", 12), (4, "mptc", 8), (5, "mptc", 8)])
+@pytest.mark.parametrize("cfg,kind,n", [(2, "id", 24), (3, "mptc", 12), (4, "mptc", 8), (5, "mptc", 8), (3, "pc", 24)])
 def test_quad_kernel_math_emulated_on_host(cfg, kind, n):
     """wbc_quad.hpp (4 lanes = 4 legs per robot) with the quad emulated by 4 host threads."""
     b = workloads.make_batch(cfg, n=n)
@@ -94,3 +94,13 @@ def test_quad_all_contact_masks_on_host():
         assert (st == 0).all()
         assert rel_err(tau, tau_o).max() < 1e-5
         assert np.allclose(met, met_o, rtol=1e-7, atol=1e-8)
+
+
+def test_pc_enforces_passivity_where_mptc_does_not():
+    """pc_controller.py: Vdot <= 0 is a hard row; MPTC only logs Vdot."""
+    b = workloads.make_batch(3, n=128)
+    t = orc.load_model_json("mini_cheetah")
+    _, met_m, _, _ = ht.run("mptc", t["flat"], b["q"], b["v"], b["targets"], b["mask"])
+    tau_p, met_p, st_p, _ = ht.run("pc", t["flat"], b["q"], b["v"], b["targets"], b["mask"])
+    assert (met_m[3] > 1e-6).sum() >= 3            # the batch does contain Vdot > 0 cases
+    assert (st_p == 0).all() and met_p[3].max() < 1e-9

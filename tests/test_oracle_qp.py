@@ -184,3 +184,30 @@ def test_step_batch_matches_single_and_is_position_invariant():
     perm = np.random.default_rng(0).permutation(24)
     tau2, _, _ = orc.step_batch("mptc", m, p, b["q"][:, perm], b["v"][:, perm], b["targets"][:, perm], b["mask"][perm])
     assert np.array_equal(tau2, tau[:, perm])
+
+
+def test_pc_law_literal_qp():
+    """pc_controller.py: x = [vd; tau; f; delta], rows Vdot <= delta and delta <= 0, no cost on delta."""
+    b, q, v, tg, ct = tick_inputs(3, 9)
+    m = orc.model(b["model"]); p = orc.params("pc")
+    found = False
+    for i in range(40):
+        b, q, v, tg, ct = tick_inputs(3, i)
+        t_m, met_m, st_m = orc.control_law("mptc", m, p, q, v, tg, ct)
+        tau, met, st, qp = orc.control_law("pc", m, p, q, v, tg, ct, want_qp=True)
+        assert st == 0
+        n, nc = qp["n"], qp["nc"]
+        assert n == 31 + 3 * nc and qp["mi"] == 4 * nc + 2
+        x = qp["x"]
+        assert (qp["Ain"] @ x - qp["bin"]).max() < 1e-9 and np.abs(qp["Aeq"] @ x - qp["beq"]).max() < 1e-9
+        assert abs(x[-1]) < 1e-9                       # delta = 0 (cost-free slack, tie-broken to 0)
+        assert met[3] < 1e-9                           # logged Vdot obeys the constraint
+        # the Vdot row evaluated at the solution equals the logged Vdot
+        vd_row = qp["Ain"][4 * nc] @ x + x[-1] - qp["bin"][4 * nc]
+        assert abs(vd_row - met[3]) < 1e-8 * (1 + abs(met[3]))
+        if met_m[3] > 1e-6:
+            found = True
+            assert np.abs(tau - t_m).max() > 1e-6      # the row is active: torques differ from MPTC
+        else:
+            assert np.allclose(tau, t_m, atol=1e-7)    # inactive: identical to MPTC
+    assert found

@@ -44,6 +44,7 @@ static int run_one(int kind, const wbc::ModelC& m, const wbc::ParamsC& P, int i,
   auto ot = [&](int k, T x) { tau[(size_t)k * stride + i] = val<T>(x); };
   auto om = [&](int k, T x) { if (met) met[(size_t)k * stride + i] = val<T>(x); };
   if (kind == wbc::KIND_ID) return wbc::tick<T, wbc::KIND_ID>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
+  if (kind == wbc::KIND_PC) return wbc::tick<T, wbc::KIND_PC>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
   return wbc::tick<T, wbc::KIND_MPTC>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
 }
 
@@ -95,6 +96,7 @@ int host_tick_count(int kind, const double* flat215, const double* params12, int
     auto om = [&](int k, Cnt x) { m1[k] = x.v; };
     Cnt muv(mu ? mu[i] : P.mu), msv(mass_scale ? mass_scale[i] : 1.0);
     if (kind == wbc::KIND_ID) wbc::tick<Cnt, wbc::KIND_ID>(m, P, in, mask[i], muv, msv, ot, om, &it);
+    else if (kind == wbc::KIND_PC) wbc::tick<Cnt, wbc::KIND_PC>(m, P, in, mask[i], muv, msv, ot, om, &it);
     else wbc::tick<Cnt, wbc::KIND_MPTC>(m, P, in, mask[i], muv, msv, ot, om, &it);
   }
   (void)tau; (void)met;
@@ -186,6 +188,7 @@ extern "C" int host_quad_batch(int kind, const double* flat215, const double* pa
       wbc::LegKin<double> K;
       wbc::StageReg<double> sg;
       if (kind == wbc::KIND_ID) st = wbc::quad_tick<QuadHost, wbc::KIND_ID>(m, P, qo, in, mask[i], mui, msi, K, sg, sh, ot, om, &it);
+      else if (kind == wbc::KIND_PC) st = wbc::quad_tick<QuadHost, wbc::KIND_PC>(m, P, qo, in, mask[i], mui, msi, K, sg, sh, ot, om, &it);
       else st = wbc::quad_tick<QuadHost, wbc::KIND_MPTC>(m, P, qo, in, mask[i], mui, msi, K, sg, sh, ot, om, &it);
       if (l == 0) { if (status) status[i] = st; if (iters) iters[i] = it; }
     }
