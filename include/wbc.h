@@ -9,6 +9,7 @@
  *         controllers/inverse_dynamics_controller.py:103-234   (kind = WBC_KIND_ID)
  *         controllers/mptc_controller.py:125-310               (kind = WBC_KIND_MPTC)
  *         controllers/pc_controller.py:44-255                  (kind = WBC_KIND_PC)
+ *         controllers/clf_controller.py:48-234                 (kind = WBC_KIND_CLF)
  *
  * i.e. everything between the reference's `quad_state` / `trunk_input` input ports and its
  * `quad_torques` / `output_metrics` output ports (basic_controller.py:33-50,
@@ -44,6 +45,7 @@ extern "C" {
 #define WBC_KIND_ID 0
 #define WBC_KIND_MPTC 1
 #define WBC_KIND_PC 2 /* controllers/pc_controller.py:44-255: MPTC + passivity row Vdot <= 0 */
+#define WBC_KIND_CLF 3 /* controllers/clf_controller.py:48-234: CLF-QP (runs on the lane-per-robot kernel) */
 
 #define WBC_MODEL_FLAT 215
 #define WBC_NQ 19
@@ -125,7 +127,8 @@ int wbc_stats_get(wbc_handle h, wbc_stats* out);
 int wbc_stats_reset(wbc_handle h);
 
 /* Kernel variant: 0 = auto (default), 1 = lane-per-robot, 2 = quad-per-robot (4 lanes = 4 legs).
- * Both compute the same tick; auto picks quad unless the optional torque box is enabled. */
+ * Both compute the same tick; auto picks quad unless the optional torque box is enabled or the
+ * kind is WBC_KIND_CLF (13 reduced variables: lane kernel only). */
 int wbc_set_variant(wbc_handle h, int variant);
 
 /* Kernel resource report for the handle's kind: registers, scratch bytes/lane, LDS bytes. */

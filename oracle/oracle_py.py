@@ -60,6 +60,7 @@ def lib():
         _LIB.orc_id_control_law.restype = C.c_int
         _LIB.orc_mptc_control_law.restype = C.c_int
         _LIB.orc_pc_control_law.restype = C.c_int
+        _LIB.orc_clf_control_law.restype = C.c_int
         _LIB.orc_step_batch.restype = C.c_int
     return _LIB
 
@@ -86,12 +87,14 @@ def model(name_or_table):
 
 
 def kind_index(kind):
-    return 0 if kind in (0, "id", "ID") else (2 if kind in (2, "pc", "PC") else 1)
+    if isinstance(kind, str):
+        return {"id": 0, "mptc": 1, "pc": 2, "clf": 3}[kind.lower()]
+    return int(kind)
 
 
 def params(kind):
     p = OrcParams()
-    if kind in (0, "id", "ID"):
+    if kind_index(kind) in (0, 3):       # CLF inherits from IDController (clf_controller.py:3)
         lib().orc_params_id_default(C.byref(p))
     else:
         lib().orc_params_mptc_default(C.byref(p))
@@ -154,8 +157,8 @@ def control_law(kind, m, p, q, v, targets, contact, want_qp=False):
     ct = (C.c_int * 4)(*[int(bool(c)) for c in contact])
     tau = np.zeros(12); met = np.zeros(4)
     qp = OrcQP() if want_qp else None
-    fn = (lib().orc_id_control_law if kind in (0, "id", "ID") else
-          lib().orc_pc_control_law if kind in (2, "pc", "PC") else lib().orc_mptc_control_law)
+    fn = [lib().orc_id_control_law, lib().orc_mptc_control_law, lib().orc_pc_control_law,
+          lib().orc_clf_control_law][kind_index(kind)]
     st = fn(C.byref(m), C.byref(p), _p(q), _p(v), _p(targets), ct, _p(tau), _p(met),
             C.byref(qp) if want_qp else None)
     if not want_qp:

@@ -953,6 +953,130 @@ int orc_pc_control_law(const orc_model* m, const orc_params* p, const double* q,
   return mptc_like_control_law(m, p, q, v, targets, contact, tau, metrics, qp_out, 1);
 }
 
+
+/* ------------------------------------------------------------------ CLF law */
+void orc_clf_care(double qp, double qd, double r, double* p11, double* p12, double* p22) {
+  /* F = [[0 1],[0 0]], G = [0;1]:  0 = F'P + PF - P G R^-1 G' P + Q  ->
+   *   p12^2 / r = qp ;  2 p12 - p22^2 / r + qd = 0 ;  p11 = p12 p22 / r            */
+  *p12 = sqrt(qp * r);
+  *p22 = sqrt(r * (qd + 2.0 * *p12));
+  *p11 = *p12 * *p22 / r;
+}
+
+/* clf_controller.py:48-234 */
+int orc_clf_control_law(const orc_model* m, const orc_params* p, const double* q, const double* v,
+                        const double* targets, const int* contact, double* tau, double* metrics,
+                        orc_qp* qp_out) {
+  /* :65-73 tuning literals */
+  const double Q_body_p = 5000.0, Q_body_pd = 200.0, Q_body_rpy = 5000.0, Q_body_rpyd = 200.0;
+  const double Q_foot_p = 200.0, Q_foot_pd = 20.0, rr = 1.0, w_delta = 1000.0;
+  tick_common Ts, *T = &Ts;
+  orc_qp qps, *qp = qp_out ? qp_out : &qps;
+  tick_head(m, q, v, targets, contact, T);
+  int nc = T->nc, ns = T->ns, n = 31 + 3 * nc, mt = 6 + 3 * ns;
+  /* :131-137 J, Jdv */
+  double J[18 * 18], Jdv[18];
+  memset(J, 0, sizeof J);
+  memcpy(J, T->J_body, sizeof(double) * 6 * 18);
+  for (int i = 0; i < 6; i++) Jdv[i] = T->Jdv_body[i];
+  for (int s = 0; s < ns; s++) {
+    memcpy(J + (6 + 3 * s) * 18, T->J_feet[T->sidx[s]], sizeof(double) * 3 * 18);
+    for (int i = 0; i < 3; i++) Jdv[6 + 3 * s + i] = T->Jdv_feet[T->sidx[s]][i];
+  }
+  /* :139-157 task-space states and errors (same construction as the MPTC law) */
+  double x[18], xd[18], x_nom[18], xd_nom[18], xdd_nom[18], xt[18], xdt[18], t3[3];
+  for (int i = 0; i < 3; i++) { x[i] = T->rpy[i]; x[3 + i] = T->p_body[i]; x_nom[i] = T->rpy_nom[i]; x_nom[3 + i] = T->p_body_nom[i]; }
+  mat3_vec(T->E, T->rpyd, t3);      for (int i = 0; i < 3; i++) { xd[i] = t3[i]; xd[3 + i] = T->pd_body[i]; }
+  mat3_vec(T->E, T->rpyd_nom, t3);  for (int i = 0; i < 3; i++) { xd_nom[i] = t3[i]; xd_nom[3 + i] = T->pd_body_nom[i]; }
+  mat3_vec(T->E, T->rpydd_nom, t3); for (int i = 0; i < 3; i++) { xdd_nom[i] = t3[i]; xdd_nom[3 + i] = T->pdd_body_nom[i]; }
+  for (int s = 0; s < ns; s++) {
+    int f = T->sidx[s];
+    for (int i = 0; i < 3; i++) {
+      x[6 + 3 * s + i] = T->p_feet[f][i];  x_nom[6 + 3 * s + i] = T->p_f_nom[f][i];
+      xd[6 + 3 * s + i] = T->pd_feet[f][i]; xd_nom[6 + 3 * s + i] = T->pd_f_nom[f][i];
+      xdd_nom[6 + 3 * s + i] = T->pdd_f_nom[f][i];
+    }
+  }
+  for (int i = 0; i < mt; i++) { xt[i] = x[i] - x_nom[i]; xdt[i] = xd[i] - xd_nom[i]; }
+  /* :159-189 Q, R, CARE -> P (block diagonal per task dimension), gamma */
+  double P11[18], P12[18], P22[18], qmin = 1e300, pmax = 0;
+  for (int i = 0; i < mt; i++) {
+    double qp_i = (i < 3) ? Q_body_rpy : (i < 6 ? Q_body_p : Q_foot_p);
+    double qd_i = (i < 3) ? Q_body_rpyd : (i < 6 ? Q_body_pd : Q_foot_pd);
+    orc_clf_care(qp_i, qd_i, rr, &P11[i], &P12[i], &P22[i]);
+    if (qp_i < qmin) qmin = qp_i;
+    if (qd_i < qmin) qmin = qd_i;
+    double h = 0.5 * (P11[i] + P22[i]), d = 0.5 * (P11[i] - P22[i]);
+    double ev = h + sqrt(d * d + P12[i] * P12[i]);
+    if (ev > pmax) pmax = ev;
+  }
+  double gamma = qmin / pmax; /* :188 */
+  /* :199 xdd_des = xdd_nom - R^-1 G'P eta ;  :15-25 a = 2 eta'PG J */
+  double xdd_des[18], gt[18], V = 0, ePFe = 0;
+  for (int i = 0; i < mt; i++) {
+    double pg = P12[i] * xt[i] + P22[i] * xdt[i];
+    xdd_des[i] = xdd_nom[i] - pg / rr;
+    gt[i] = 2.0 * pg;
+    V += P11[i] * xt[i] * xt[i] + 2.0 * P12[i] * xt[i] * xdt[i] + P22[i] * xdt[i] * xdt[i];
+    ePFe += P11[i] * xt[i] * xdt[i] + P12[i] * xdt[i] * xdt[i];
+  }
+  memset(qp->Q, 0, sizeof qp->Q); memset(qp->c, 0, sizeof qp->c);
+  memset(qp->Als, 0, sizeof qp->Als); memset(qp->bls, 0, sizeof qp->bls);
+  /* :200 AddJacobianTypeCost(J, vd, Jdv, xdd_des, 1.0) ; :203 AddVdotCost ; :206 w_delta delta^2 */
+  for (int i = 0; i < 18; i++) {
+    for (int j = 0; j < 18; j++) {
+      double s = 0;
+      for (int a = 0; a < mt; a++) s += J[a * 18 + i] * J[a * 18 + j];
+      qp->Q[i * n + j] = s;
+    }
+    double s = 0;
+    for (int a = 0; a < mt; a++) s += J[a * 18 + i] * (Jdv[a] - xdd_des[a] + gt[a]);
+    qp->c[i] = s;
+  }
+  qp->Q[(n - 1) * n + n - 1] = 2.0 * w_delta;
+  /* square-root form: 1/2 |J vd - (xdd_des - Jdv - gt)|^2 + 1/2 (sqrt(2 w) delta)^2 */
+  for (int a = 0; a < mt; a++) {
+    for (int j = 0; j < 18; j++) qp->Als[a * n + j] = J[a * 18 + j];
+    qp->bls[a] = xdd_des[a] - Jdv[a] - gt[a];
+  }
+  if (mt < 18) {
+    qp->Als[mt * n + n - 1] = sqrt(2.0 * w_delta);
+    qp->bls[mt] = 0.0;
+    qp->mls = mt + 1;
+  } else {
+    /* nc = 0: all 18 task rows are in use; fold the delta row into the tie-break weights below */
+    qp->mls = mt;
+  }
+  build_constraints(T, p, v, qp, n); /* :212-221 */
+  {
+    /* :27-45, :209 AddVdotConstraint: 2 eta'PG J vd - delta <= -gamma V - 2 eta'PF eta - 2 eta'PG (Jdv - xdd_nom) */
+    int r = qp->mi;
+    double ub = -gamma * V - 2.0 * ePFe;
+    for (int j = 0; j < 18; j++) {
+      double s = 0;
+      for (int a = 0; a < mt; a++) s += gt[a] * J[a * 18 + j];
+      qp->Ain[r * n + j] = s;
+    }
+    for (int a = 0; a < mt; a++) ub -= gt[a] * (Jdv[a] - xdd_nom[a]);
+    qp->Ain[r * n + n - 1] = -1.0;
+    qp->bin[r] = ub;
+    qp->mi += 1;
+  }
+  double dreg[ORC_NMAX];
+  for (int i = 0; i < n; i++) dreg[i] = (i >= 18 && i < n - 1) ? 1.0 : 0.0; /* tie-break on [tau; f] only */
+  if (mt == 18) dreg[n - 1] = 2.0 * w_delta / p->tiebreak_eps2;             /* exact delta cost when no LS row is left */
+  qp->status = orc_qp_solve(n, qp->mls, qp->Als, qp->bls, p->tiebreak_eps2, dreg, qp->me, qp->Aeq, qp->beq, qp->mi,
+                            qp->Ain, qp->bin, qp->x, &qp->iters, &qp->primal_res);
+  for (int k = 0; k < 12; k++) tau[k] = (qp->status == 2) ? 0.0 : qp->x[18 + k];
+  if (metrics) {
+    double err = 0, Vdot = 2.0 * ePFe, Jvd[18];
+    mv(mt, 18, J, qp->x, Jvd);
+    for (int i = 0; i < mt; i++) { err += xt[i] * xt[i]; Vdot += gt[i] * (Jvd[i] + Jdv[i] - xdd_nom[i]); }
+    metrics[0] = V; metrics[1] = err; metrics[2] = 0.0; metrics[3] = (qp->status == 2) ? 0.0 : Vdot;
+  }
+  return qp->status;
+}
+
 /* ------------------------------------------------------------------ batched driver */
 int orc_step_batch(const orc_model* m, const orc_params* p, int kind, int n, int stride, const double* q,
                    const double* v, const double* targets, const unsigned char* mask, const double* mu,
@@ -979,7 +1103,8 @@ int orc_step_batch(const orc_model* m, const orc_params* p, int kind, int n, int
     }
     int st = (kind == 0) ? orc_id_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
              : (kind == 1) ? orc_mptc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
-                           : orc_pc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL);
+             : (kind == 2) ? orc_pc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
+                           : orc_clf_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL);
     for (int k = 0; k < 12; k++) tau[(size_t)k * stride + i] = ti[k];
     if (metrics) for (int k = 0; k < 4; k++) metrics[(size_t)k * stride + i] = mi[k];
     if (status) status[i] = st;
@@ -1016,7 +1141,8 @@ int orc_bench_batch(const orc_model* m, const orc_params* p, int kind, int n, in
     }
     int st = (kind == 0) ? orc_id_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
              : (kind == 1) ? orc_mptc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
-                           : orc_pc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL);
+             : (kind == 2) ? orc_pc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
+                           : orc_clf_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL);
     if (j >= total - n) {
       for (int k = 0; k < 12; k++) tau[(size_t)k * stride + i] = ti[k];
       if (status) status[i] = st;

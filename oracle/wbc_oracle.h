@@ -111,6 +111,17 @@ int orc_pc_control_law(const orc_model* m, const orc_params* p, const double* q,
                        const double* targets, const int* contact, double* tau, double* metrics,
                        orc_qp* qp_out /* nullable */);
 
+/* controllers/clf_controller.py:48-234: CLF-QP inverse dynamics.  x = [vd; tau; f; delta].
+ * Gains are the literals of :65-73 (Q_body_p 5000, Q_body_pd 200, Q_foot_p 200, Q_foot_pd 20,
+ * r 1, w_delta 1000); mu / Kd_contact / tiebreak_eps2 come from `p`.  The CARE of :187 has the
+ * closed form of a double integrator with diagonal Q, R (checked against scipy in the tests).
+ * metrics = [V, err, 0, Vdot] (:227-230). */
+int orc_clf_control_law(const orc_model* m, const orc_params* p, const double* q, const double* v,
+                        const double* targets, const int* contact, double* tau, double* metrics,
+                        orc_qp* qp_out /* nullable */);
+/* closed-form CARE blocks for one task dimension: P = [[p11 p12],[p12 p22]] */
+void orc_clf_care(double qp, double qd, double r, double* p11, double* p12, double* p22);
+
 /* Generic dense QP used by both laws:
  *   min 1/2|Als x - bls|^2 + 1/2 eps2 sum_i dreg[i] x_i^2   s.t. Aeq x = beq, Ain x <= bin
  * (null-space elimination of the equalities, QR of the stacked square-root form,
@@ -120,7 +131,7 @@ int orc_qp_solve(int n, int mls, const double* Als, const double* bls, double ep
                  const double* bin, double* x, int* iters, double* primal_res);
 
 /* Batched driver over SoA arrays (batch index fastest), OpenMP over instances when built
- * with -fopenmp.  kind: 0 = ID, 1 = MPTC, 2 = PC.  mask bit i = foot i in contact.
+ * with -fopenmp.  kind: 0 = ID, 1 = MPTC, 2 = PC, 3 = CLF.  mask bit i = foot i in contact.
  * mu / mass_scale may be NULL.  Used by tests and by bench.py's cpu_baseline leg. */
 int orc_step_batch(const orc_model* m, const orc_params* p, int kind, int n, int stride, const double* q,
                    const double* v, const double* targets, const unsigned char* mask, const double* mu,

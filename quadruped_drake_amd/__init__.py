@@ -3,5 +3,5 @@
 Product code: csrc/ (HIP kernels + C ABI, include/wbc.h), controller.py (host-side mirror of the
 reference's IDController / MPTCController interface), workloads.py (synthetic batches of
 BASELINE.json's configs), stats.py (multi-GPU shard + RCCL statistics reduce)."""
-from .controller import IDController, MPTCController, PCController, BatchedController, SolverError, pack_trunk_input, load_model, make_leaf_system  # noqa
+from .controller import IDController, MPTCController, PCController, CLFController, BatchedController, SolverError, pack_trunk_input, load_model, make_leaf_system  # noqa
 from . import workloads  # noqa

@@ -10,7 +10,7 @@ c_double_p = C.POINTER(C.c_double)
 c_u8_p = C.POINTER(C.c_uint8)
 c_i32_p = C.POINTER(C.c_int32)
 
-KIND_ID, KIND_MPTC, KIND_PC = 0, 1, 2
+KIND_ID, KIND_MPTC, KIND_PC, KIND_CLF = 0, 1, 2, 3
 DEVICE_PTRS, HOST_PTRS = 0, 1
 
 # every symbol include/wbc.h declares

@@ -218,6 +218,11 @@ class PCController(BatchedController):
     kind = _lib.KIND_PC
 
 
+class CLFController(BatchedController):
+    """controllers/clf_controller.py:3-234 (CLF-QP inverse dynamics), batched; lane-per-robot kernel."""
+    kind = _lib.KIND_CLF
+
+
 def make_leaf_system(plant, dt, control_method="ID", model="mini_cheetah", use_lcm=False, **kw):
     """Drop-in for `IDController(plant, dt, use_lcm)` / `MPTCController(...)` in simulate.py:106-118:
     a pydrake LeafSystem with the reference's four ports (basic_controller.py:33-50,
@@ -234,7 +239,7 @@ def make_leaf_system(plant, dt, control_method="ID", model="mini_cheetah", use_l
     q_perm = [plant.GetJointByName(nm).velocity_start() - 6 for nm in joint_names]
     B = plant.MakeActuationMatrix()  # nv x nu
     act_perm = [q_perm.index(int(np.argmax(B[6:, k]))) for k in range(12)]
-    cls = {"ID": IDController, "MPTC": MPTCController, "PC": PCController}[control_method]
+    cls = {"ID": IDController, "MPTC": MPTCController, "PC": PCController, "CLF": CLFController}[control_method]
     ctrl = cls(model=table, max_batch=1, host_ptrs=True, q_perm=q_perm, act_perm=act_perm, **kw)
 
     class _Leaf(LeafSystem):

@@ -340,7 +340,7 @@ wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
 
 struct wbc_handle_s {
   int kind, max_batch, device, variant;
-  bool torque_box;
+  bool torque_box, lane_only;
   uint32_t flags;
   hipStream_t stream;
   bool own_stream;
@@ -360,7 +360,7 @@ const char* wbc_last_error(void) { return g_err; }
 int wbc_version(void) { return 100; }
 
 int wbc_params_default(int kind, wbc_params* out) {
-  if (!out || kind < WBC_KIND_ID || kind > WBC_KIND_PC) return misuse("wbc_params_default: bad argument");
+  if (!out || kind < WBC_KIND_ID || kind > WBC_KIND_CLF) return misuse("wbc_params_default: bad argument");
   static_assert(sizeof(wbc_params) == sizeof(wbc::ParamsC), "params layout");
   wbc::params_default(kind, reinterpret_cast<wbc::ParamsC*>(out));
   return 0;
@@ -369,7 +369,7 @@ int wbc_params_default(int kind, wbc_params* out) {
 int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int max_batch, int device,
                uint32_t flags, wbc_handle* out) {
   if (!model || !out) return misuse("wbc_create: null argument");
-  if (kind < WBC_KIND_ID || kind > WBC_KIND_PC) return misuse("wbc_create: kind must be WBC_KIND_ID, WBC_KIND_MPTC or WBC_KIND_PC");
+  if (kind < WBC_KIND_ID || kind > WBC_KIND_CLF) return misuse("wbc_create: kind must be WBC_KIND_ID, _MPTC, _PC or _CLF");
   if (max_batch <= 0) return misuse("wbc_create: max_batch must be positive");
   wbc::ModelC m;
   if (wbc::model_from_flat(model->flat, &m)) return misuse("wbc_create: joint axes must be axis-aligned");
@@ -395,6 +395,7 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
   h->kind = kind; h->max_batch = max_batch; h->device = device; h->flags = flags;
   h->variant = 0;
   h->torque_box = P.tau_max < 1e300;
+  h->lane_only = h->torque_box || kind == WBC_KIND_CLF;
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->own_stream = true;
   HIP_TRY(hipMalloc(&h->d_model, (size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8));
@@ -454,7 +455,7 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
                   int32_t* status) {
   // variant 0 = auto: the quad kernel (4 lanes per robot) unless the optional torque box is on,
   // which only the lane-per-robot kernel implements.
-  const bool quad = (h->variant == 2) || (h->variant == 0 && !h->torque_box);
+  const bool quad = (h->variant == 2) || (h->variant == 0 && !h->lane_only);
   dim3 block(BLOCK);
   StatsDev* d_stats = getenv("WBC_NO_STATS") ? nullptr : h->d_stats;  // diagnostic switch
 #define WBC_LAUNCH(KERNEL, GRID)                                                                              \
@@ -476,6 +477,10 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
   if (quad) {
     dim3 grid((n + QROBOTS - 1) / QROBOTS);
     WBC_LAUNCH(wbc_quad_kernel, grid);
+  } else if (h->kind == WBC_KIND_CLF) {
+    dim3 grid((n + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_CLF>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg,
+                       mask, mu, ms, tau, met, status, d_stats);
   } else {
     dim3 grid((n + BLOCK - 1) / BLOCK);
     WBC_LAUNCH(wbc_tick_kernel, grid);
@@ -582,7 +587,7 @@ int wbc_debug_stamps(unsigned long long* out, int nblocks) {
 int wbc_set_variant(wbc_handle h, int variant) {
   if (!h) return misuse("wbc_set_variant: null handle");
   if (variant < 0 || variant > 2) return misuse("wbc_set_variant: 0 = auto, 1 = lane-per-robot, 2 = quad-per-robot");
-  if (variant == 2 && h->torque_box) return misuse("wbc_set_variant: the quad kernel has no torque box (tau_max must be +inf)");
+  if (variant == 2 && h->lane_only) return misuse("wbc_set_variant: the quad kernel has no torque box / CLF law");
   h->variant = variant;
   return 0;
 }
@@ -590,12 +595,13 @@ int wbc_set_variant(wbc_handle h, int variant) {
 int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads) {
   if (!h) return misuse("wbc_kernel_info: null handle");
   hipFuncAttributes a;
-  const bool quad = (h->variant == 2) || (h->variant == 0 && !h->torque_box);
+  const bool quad = (h->variant == 2) || (h->variant == 0 && !h->lane_only);
   const void* fn;
   if (quad) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_quad_kernel<wbc::KIND_ID>
                : h->kind == WBC_KIND_MPTC ? (const void*)wbc_quad_kernel<wbc::KIND_MPTC> : (const void*)wbc_quad_kernel<wbc::KIND_PC>;
   else fn = h->kind == WBC_KIND_ID ? (const void*)wbc_tick_kernel<wbc::KIND_ID>
-          : h->kind == WBC_KIND_MPTC ? (const void*)wbc_tick_kernel<wbc::KIND_MPTC> : (const void*)wbc_tick_kernel<wbc::KIND_PC>;
+          : h->kind == WBC_KIND_MPTC ? (const void*)wbc_tick_kernel<wbc::KIND_MPTC>
+          : h->kind == WBC_KIND_PC ? (const void*)wbc_tick_kernel<wbc::KIND_PC> : (const void*)wbc_tick_kernel<wbc::KIND_CLF>;
   HIP_TRY(hipFuncGetAttributes(&a, fn));
   if (num_vgpr) *num_vgpr = a.numRegs;
   if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;

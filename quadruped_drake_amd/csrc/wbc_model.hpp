@@ -48,7 +48,7 @@ inline void model_set_perms(ModelC* m, const int* q_perm, const int* act_perm) {
 
 inline void params_default(int kind, ParamsC* p) {
   // inverse_dynamics_controller.py:117-127 / mptc_controller.py:143-153; mu :19 / :20; Kd :93 / :115
-  if (kind == KIND_ID) {
+  if (kind == KIND_ID || kind == KIND_CLF) {  // CLF inherits IDController; its own gains are literals in the law
     p->Kp_body_p = 500.0; p->Kd_body_p = 50.0; p->Kp_body_rpy = 500.0; p->Kd_body_rpy = 50.0;
     p->Kp_foot = 100.0; p->Kd_foot = 20.0;
   } else {

@@ -67,7 +67,9 @@ WBC_HD void wbc_sincos(double x, double& s, double& c) {
 }
 template <class T> WBC_HD void wbc_sincos(const T& x, T& s, T& c) { s = sin(x); c = cos(x); }
 
-enum { KIND_ID = 0, KIND_MPTC = 1, KIND_PC = 2 };  // PC = MPTC + the passivity row Vdot <= 0 (pc_controller.py)
+enum { KIND_ID = 0, KIND_MPTC = 1, KIND_PC = 2, KIND_CLF = 3 };
+// PC = MPTC + the passivity row Vdot <= 0 (pc_controller.py); CLF = ID-type cost with LQR feedback, a
+// slack delta (13th reduced variable) and the CLF row (clf_controller.py) -- lane kernel only.
 enum { ST_OK = 0, ST_ITER = 1, ST_SINGULAR = 2 };
 
 struct LinkC {
@@ -359,12 +361,12 @@ template <class T> WBC_HD void mm3(const T* A, const T* B, T* C) {
 template <class T> WBC_HD T wabs(const T& x) { return x < T(0.0) ? T(0.0) - x : x; }
 
 // ---------------------------------------------------------------- QR + Goldfarb-Idnani (n = 12)
-enum { NZ = 12, MAXC = 41, PC_ROW = 40 };
+enum { NZ = 12, MAXC = 42, PC_ROW = 40, CLF_ROW = 41 };
 
 // Fold a block of `p` dense rows A[p][13] (12 coefficients + rhs) into the upper-triangular
 // factor R[12][13] by Householder reflections on [R_kk; A_0k..A_pk].
-template <class T> WBC_HD void qr_append(T (*R)[NZ + 1], T (*A)[NZ + 1], int p) {
-  for (int k = 0; k < NZ; k++) {
+template <class T, int NV> WBC_HD void qr_append(T (*R)[NV + 1], T (*A)[NV + 1], int p) {
+  for (int k = 0; k < NV; k++) {
     T s2 = T(0.0);
     for (int i = 0; i < p; i++) s2 = s2 + A[i][k] * A[i][k];
     if (!(s2 > T(0.0))) continue;
@@ -374,7 +376,7 @@ template <class T> WBC_HD void qr_append(T (*R)[NZ + 1], T (*A)[NZ + 1], int p) 
     T v0 = rkk - alpha;            // Householder vector [v0; A[:,k]]
     T beta = T(1.0) / (s2 + v0 * v0) * T(2.0);
     R[k][k] = alpha;
-    for (int j = k + 1; j <= NZ; j++) {
+    for (int j = k + 1; j <= NV; j++) {
       T s = v0 * R[k][j];
       for (int i = 0; i < p; i++) s = s + A[i][k] * A[i][j];
       s = s * beta;
@@ -389,16 +391,18 @@ template <class T> WBC_HD void qr_append(T (*R)[NZ + 1], T (*A)[NZ + 1], int p) 
 template <class T> struct QpCons {
   T fr[4][3];         // per contact-slot... (unused entries zero)
   T mu_n, inv_s;      // mu / sqrt(1+mu^2), 1/sqrt(1+mu^2)
-  const T (*Trow)[NZ + 1];  // T | t0 rows for the torque box (nullable)
+  const T* Trow;      // torque map rows [12][tstride]: coefficients then t0 (torque box; nullable)
+  int tstride;
   T tau_max;
   T tnorm[12];
   unsigned mask;
   const T* pcrow;  // PC law: Vdot(z) = pcrow[0..11].z + pcrow[12] <= 0 (nullable)
   T pc_inv;        // 1 / |pcrow[0..11]|
+  const T* clfrow; // CLF law: clfrow[0..12].[z; delta] <= clfrow[13], already normalised (nullable)
 };
 
-template <class T> WBC_HD void cons_normal(const QpCons<T>& C, int i, T* n, T& b) {
-  for (int k = 0; k < NZ; k++) n[k] = T(0.0);
+template <class T, int NV> WBC_HD void cons_normal(const QpCons<T>& C, int i, T* n, T& b) {
+  for (int k = 0; k < NV; k++) n[k] = T(0.0);
   if (i < 16) {
     int l = i >> 2, r = i & 3;
     // rows: +fx - mu fz <= 0, -fx - mu fz <= 0, +fy - mu fz <= 0, -fy - mu fz <= 0  ->  n.z >= 0
@@ -410,54 +414,58 @@ template <class T> WBC_HD void cons_normal(const QpCons<T>& C, int i, T* n, T& b
   } else if (i == PC_ROW) {
     for (int k = 0; k < NZ; k++) n[k] = T(0.0) - C.pcrow[k] * C.pc_inv;
     b = C.pcrow[NZ] * C.pc_inv;
+  } else if (i == CLF_ROW) {
+    for (int k = 0; k < NV; k++) n[k] = T(0.0) - C.clfrow[k];
+    b = T(0.0) - C.clfrow[NV];
   } else {
     int j = (i - 16) >> 1;
     T sg = ((i - 16) & 1) ? T(1.0) : T(-1.0);   // even: tau_j <= tau_max -> -T_j z >= t0_j - tau_max
     T inv = T(1.0) / C.tnorm[j];
-    for (int k = 0; k < NZ; k++) n[k] = sg * C.Trow[j][k] * inv;
-    b = (T(0.0) - sg * C.Trow[j][NZ] - C.tau_max) * inv;
+    const T* row = C.Trow + j * C.tstride;
+    for (int k = 0; k < NZ; k++) n[k] = sg * row[k] * inv;
+    b = (T(0.0) - sg * row[C.tstride - 1] - C.tau_max) * inv;
   }
 }
 
 // Goldfarb-Idnani.  J = R^-1 (12x12), z = unconstrained minimiser.  `elig` = bitmask of
 // constraints that exist.  Returns status, iteration count in *iters.
-template <class T>
-WBC_HD int gi_solve(T (*J)[NZ], T* z, const QpCons<T>& C, unsigned long long elig, int* iters_out) {
-  int A[NZ], q = 0;
+template <class T, int NV>
+WBC_HD int gi_solve(T (*J)[NV], T* z, const QpCons<T>& C, unsigned long long elig, int* iters_out) {
+  int A[NV], q = 0;
   unsigned long long active = 0ull;
-  T u[NZ + 1], Rq[NZ][NZ], d[NZ], zd[NZ], r[NZ], np[NZ];
+  T u[NV + 1], Rq[NV][NV], d[NV], zd[NV], r[NV], np[NV];
   int iters = 0;
   const int maxit = 200;
   for (;;) {
     T zinf = T(0.0);
-    for (int i = 0; i < NZ; i++) { T a = wabs(z[i]); if (a > zinf) zinf = a; }
+    for (int i = 0; i < NV; i++) { T a = wabs(z[i]); if (a > zinf) zinf = a; }
     T tol = T(1e-13) * (T(1.0) + zinf);
     int p = -1;
     T sp = T(0.0) - tol, bp = T(0.0);
     for (int i = 0; i < MAXC; i++) {
       if (!((elig >> i) & 1ull) || ((active >> i) & 1ull)) continue;
-      T n[NZ], b;
-      cons_normal(C, i, n, b);
+      T n[NV], b;
+      cons_normal<T, NV>(C, i, n, b);
       T s = T(0.0) - b;
-      for (int k = 0; k < NZ; k++) s = s + n[k] * z[k];
+      for (int k = 0; k < NV; k++) s = s + n[k] * z[k];
       if (s < sp) { sp = s; p = i; }
     }
     if (p < 0) { *iters_out = iters; return ST_OK; }
-    cons_normal(C, p, np, bp);
+    cons_normal<T, NV>(C, p, np, bp);
     u[q] = T(0.0);
     for (;;) {
       if (++iters > maxit) { *iters_out = iters; return ST_ITER; }
       T dn = T(0.0), d2n = T(0.0);
-      for (int k = 0; k < NZ; k++) {
+      for (int k = 0; k < NV; k++) {
         T s = T(0.0);
-        for (int i = 0; i < NZ; i++) s = s + J[i][k] * np[i];
+        for (int i = 0; i < NV; i++) s = s + J[i][k] * np[i];
         d[k] = s;
         dn = dn + s * s;
         if (k >= q) d2n = d2n + s * s;
       }
-      for (int i = 0; i < NZ; i++) {
+      for (int i = 0; i < NV; i++) {
         T s = T(0.0);
-        for (int k = q; k < NZ; k++) s = s + J[i][k] * d[k];
+        for (int k = q; k < NV; k++) s = s + J[i][k] * d[k];
         zd[i] = s;
       }
       for (int k = q - 1; k >= 0; k--) {
@@ -473,11 +481,11 @@ WBC_HD int gi_solve(T (*J)[NZ], T* z, const QpCons<T>& C, unsigned long long eli
           T c = u[k] / r[k];
           if (!have_t1 || c < t1) { t1 = c; l = k; have_t1 = true; }
         }
-      bool dependent = !(d2n > T(1e-22) * dn) || q == NZ;
+      bool dependent = !(d2n > T(1e-22) * dn) || q == NV;
       T t2 = T(0.0);
       if (!dependent) {
         T znp = T(0.0);
-        for (int i = 0; i < NZ; i++) znp = znp + zd[i] * np[i];
+        for (int i = 0; i < NV; i++) znp = znp + zd[i] * np[i];
         t2 = (T(0.0) - sp) / znp;
       }
       if (dependent && !have_t1) { *iters_out = iters; return ST_SINGULAR; }
@@ -486,14 +494,14 @@ WBC_HD int gi_solve(T (*J)[NZ], T* z, const QpCons<T>& C, unsigned long long eli
       for (int k = 0; k < q; k++) u[k] = u[k] - t * r[k];
       u[q] = u[q] + t;
       if (!dependent)
-        for (int i = 0; i < NZ; i++) z[i] = z[i] + t * zd[i];
+        for (int i = 0; i < NV; i++) z[i] = z[i] + t * zd[i];
       if (full) {
-        for (int j = NZ - 1; j > q; j--) {
+        for (int j = NV - 1; j > q; j--) {
           T a = d[j - 1], bb = d[j];
           if (bb == T(0.0)) continue;
           T h = sqrt(a * a + bb * bb), c = a / h, s = bb / h;
           d[j - 1] = h; d[j] = T(0.0);
-          for (int i = 0; i < NZ; i++) {
+          for (int i = 0; i < NV; i++) {
             T x = J[i][j - 1], y = J[i][j];
             J[i][j - 1] = c * x + s * y;
             J[i][j] = c * y - s * x;
@@ -523,7 +531,7 @@ WBC_HD int gi_solve(T (*J)[NZ], T* z, const QpCons<T>& C, unsigned long long eli
           Rq[j][k] = c * x + s * y;
           Rq[j + 1][k] = c * y - s * x;
         }
-        for (int i = 0; i < NZ; i++) {
+        for (int i = 0; i < NV; i++) {
           T x = J[i][j], y = J[i][j + 1];
           J[i][j] = c * x + s * y;
           J[i][j + 1] = c * y - s * x;
@@ -531,7 +539,7 @@ WBC_HD int gi_solve(T (*J)[NZ], T* z, const QpCons<T>& C, unsigned long long eli
       }
       if (!dependent) {
         sp = T(0.0) - bp;
-        for (int k = 0; k < NZ; k++) sp = sp + np[k] * z[k];
+        for (int k = 0; k < NV; k++) sp = sp + np[k] * z[k];
       }
     }
   }
@@ -576,6 +584,7 @@ template <class T> WBC_HD void lu6_solve(const T (*A)[6], const int* piv, T* b) 
 template <class T, int KIND, class In, class OutTau, class OutMet>
 WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T mass_scale, OutTau out_tau,
                 OutMet out_met, int* iters_out) {
+  constexpr int NV = (KIND == KIND_CLF) ? NZ + 1 : NZ;  // reduced variables: z (12) [+ delta for CLF]
   int status = ST_OK;
   // ---- state
   T qw = in(0), qx = in(1), qy = in(2), qz = in(3);
@@ -741,7 +750,8 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     }
   }
   // ---- torque map tau = Tm z + t0 (canonical joint order), rows 3l..3l+2
-  T Tm[NZ][NZ + 1];
+  T Tm[NZ][NV + 1];
+  for (int i = 0; i < NZ; i++) for (int c = NZ; c < NV; c++) Tm[i][c] = T(0.0);
   for (int l = 0; l < 4; l++) {
     bool ct = (mask >> l) & 1;
     for (int i = 0; i < 3; i++) {
@@ -753,7 +763,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       T s = D[l].hl[i];
       for (int j = 0; j < 6; j++) s = s + Y[l][6 * i + j] * ab0[j];
       if (ct) s = s + Pm[l][3 * i] * bc[l][0] + Pm[l][3 * i + 1] * bc[l][1] + Pm[l][3 * i + 2] * bc[l][2];
-      Tm[3 * l + i][NZ] = s;
+      Tm[3 * l + i][NV] = s;
       for (int j = 0; j < 3; j++)
         Tm[3 * l + i][3 * l + j] = Tm[3 * l + i][3 * l + j] + (ct ? (T(0.0) - D[l].Jl[3 * j + i]) : Pm[l][3 * i + j]);
     }
@@ -762,9 +772,12 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
   // ---- level-1 rows into the QR factor.  R starts as the diagonal rows:
   //      swing leg: sqrt(w_foot) (z_l - target)  [ID only];  contact leg: eps f_l
   T eps = sqrt(T(P.eps2));
-  T Rf[NZ][NZ + 1];
-  for (int i = 0; i < NZ; i++) for (int j = 0; j <= NZ; j++) Rf[i][j] = T(0.0);
-  T blk[6][NZ + 1];
+  T Rf[NV][NV + 1];
+  for (int i = 0; i < NV; i++) for (int j = 0; j <= NV; j++) Rf[i][j] = T(0.0);
+  T blk[6][NV + 1];
+  for (int i = 0; i < 6; i++) for (int c = NZ; c < NV; c++) blk[i][c] = T(0.0);
+  T clfrow[NZ + 3];
+  T clf_c0 = T(0.0), clf_gb[6], clf_gs[4][3];  // CLF logging: Vdot = clf_c0 + clf_gb.(a_b) + sum clf_gs.z_sw
   T met_V = T(0.0), met_err = T(0.0), met_Vdot = T(0.0);
   // task errors (needed by both laws for logging)
   T xt_b[6], xdt_b[6];
@@ -789,15 +802,84 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
         T tp = in(37 + 18 + 9 * l + i), tpd = in(37 + 21 + 9 * l + i), tpdd = in(37 + 24 + 9 * l + i);
         T des = tpdd - T(P.Kp_foot) * (pf - tp) - T(P.Kd_foot) * (D[l].pd[i] - tpd);
         Rf[3 * l + i][3 * l + i] = sw_f;
-        Rf[3 * l + i][NZ] = sw_f * (des - D[l].Jdv[i]);
+        Rf[3 * l + i][NV] = sw_f * (des - D[l].Jdv[i]);
         met_err = met_err + (pf - tp) * (pf - tp);
       }
     }
     for (int i = 0; i < 6; i++) {
       for (int c = 0; c < NZ; c++) blk[i][c] = sw_b * B[i][c];
-      blk[i][NZ] = sw_b * (ades[i] - ab0[i]);
+      blk[i][NV] = sw_b * (ades[i] - ab0[i]);
     }
-    qr_append(Rf, blk, 6);
+    qr_append<T, NV>(Rf, blk, 6);
+  } else if (KIND == KIND_CLF) {
+    // ---------------- CLF-QP (clf_controller.py:48-234) in task coordinates, weights 1 on every task row
+    const T Qp_b = T(5000.0), Qd_b = T(200.0), Qp_f = T(200.0), Qd_f = T(20.0), rr = T(1.0), w_delta = T(1000.0);  // :65-73
+    T pb11, pb12, pb22, pf11, pf12, pf22;  // closed-form CARE per task dimension (:187)
+    pb12 = sqrt(Qp_b * rr); pb22 = sqrt(rr * (Qd_b + T(2.0) * pb12)); pb11 = pb12 * pb22 / rr;
+    pf12 = sqrt(Qp_f * rr); pf22 = sqrt(rr * (Qd_f + T(2.0) * pf12)); pf11 = pf12 * pf22 / rr;
+    T om_rt[3], xdn[3], xddn[3], xdd_b[6];
+    rotv(E, rpyd, om_rt);
+    rotv(E, tg_rpyd, xdn);
+    rotv(E, tg_rpydd, xddn);
+    for (int i = 0; i < 3; i++) {
+      xdt_b[i] = om_rt[i] - xdn[i];
+      xdt_b[3 + i] = v0[i] - tg_pdb[i];
+      xdd_b[i] = xddn[i];
+      xdd_b[3 + i] = tg_pddb[i];
+    }
+    bool any_swing = false;
+    T V = T(0.0), ePFe = T(0.0), ub = T(0.0), gb_ab0 = T(0.0), row2 = T(1.0);  // row2 = |coefficients|^2 (delta: 1)
+    for (int c = 0; c < NV; c++) clfrow[c] = T(0.0);
+    for (int i = 0; i < 6; i++) {
+      T pg = pb12 * xt_b[i] + pb22 * xdt_b[i];
+      T gt = T(2.0) * pg;
+      clf_gb[i] = gt;
+      V = V + pb11 * xt_b[i] * xt_b[i] + T(2.0) * pb12 * xt_b[i] * xdt_b[i] + pb22 * xdt_b[i] * xdt_b[i];
+      ePFe = ePFe + pb11 * xt_b[i] * xdt_b[i] + pb12 * xdt_b[i] * xdt_b[i];
+      ub = ub + gt * xdd_b[i];                         // -gt (Jdv - xdd_nom), Jdv_body = 0
+      T ystar = xdd_b[i] - pg / rr - gt;               // xdd_des - Jdv - gt
+      for (int c = 0; c < NZ; c++) { blk[i][c] = B[i][c]; clfrow[c] = clfrow[c] + gt * B[i][c]; }
+      blk[i][NV] = ystar - ab0[i];
+      gb_ab0 = gb_ab0 + gt * ab0[i];
+    }
+    for (int l = 0; l < 4; l++) {
+      bool ct = (mask >> l) & 1;
+      for (int i = 0; i < 3; i++) {
+        clf_gs[l][i] = T(0.0);
+        if (ct) { Rf[3 * l + i][3 * l + i] = eps; continue; }
+        any_swing = true;
+        T pf = p0[i] + K[l].rf(i);
+        T xt = pf - in(37 + 18 + 9 * l + i), xdt = D[l].pd[i] - in(37 + 21 + 9 * l + i), xddn_s = in(37 + 24 + 9 * l + i);
+        T pg = pf12 * xt + pf22 * xdt, gt = T(2.0) * pg;
+        clf_gs[l][i] = gt;
+        V = V + pf11 * xt * xt + T(2.0) * pf12 * xt * xdt + pf22 * xdt * xdt;
+        ePFe = ePFe + pf11 * xt * xdt + pf12 * xdt * xdt;
+        ub = ub - gt * (D[l].Jdv[i] - xddn_s);
+        Rf[3 * l + i][3 * l + i] = T(1.0);
+        Rf[3 * l + i][NV] = xddn_s - pg / rr - D[l].Jdv[i] - gt;
+        clfrow[3 * l + i] = clfrow[3 * l + i] + gt;
+        met_err = met_err + xt * xt;
+      }
+    }
+    Rf[NZ][NZ] = sqrt(T(2.0) * w_delta);                // w_delta delta^2 = 1/2 (sqrt(2 w) delta)^2   (:206)
+    // gamma = min eig(Q) / max eig(P) over the task dimensions that exist (:188)
+    T hb = T(0.5) * (pb11 + pb22), db = T(0.5) * (pb11 - pb22), evb = hb + sqrt(db * db + pb12 * pb12);
+    T hf = T(0.5) * (pf11 + pf22), df = T(0.5) * (pf11 - pf22), evf = hf + sqrt(df * df + pf12 * pf12);
+    T qmin = any_swing ? Qd_f : Qd_b, pmax = (any_swing && evf > evb) ? evf : evb;
+    T gamma = qmin / pmax;
+    ub = ub - gamma * V - T(2.0) * ePFe - gb_ab0;       // gt.(B z + ab0) + gt_s.z_sw - delta <= ub'
+    clfrow[NZ] = T(-1.0);
+    for (int c = 0; c < NZ; c++) row2 = row2 + clfrow[c] * clfrow[c];
+    T inv = T(1.0) / sqrt(row2);
+    for (int c = 0; c < NV; c++) clfrow[c] = clfrow[c] * inv;
+    clfrow[NV] = ub * inv;
+    met_V = V;
+    clf_c0 = T(2.0) * ePFe;
+    for (int i = 0; i < 6; i++) clf_c0 = clf_c0 - clf_gb[i] * xdd_b[i];
+    for (int l = 0; l < 4; l++)
+      if (!((mask >> l) & 1))
+        for (int i = 0; i < 3; i++) clf_c0 = clf_c0 + clf_gs[l][i] * (D[l].Jdv[i] - in(37 + 24 + 9 * l + i));
+    qr_append<T, NV>(Rf, blk, 6);
   } else {
     // ---------------- MPTC (mptc_controller.py:227-292), in task coordinates
     // Task inertia (arrowhead):  Mt_bb = Gs - sum_l (Ji Jfb)' Y_l ; Mt_bl = (Ji' Y_l)' ; Mt_ll = Ji' P_l
@@ -993,12 +1075,12 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       }
       T s = c1_b[i];
       for (int j = 0; j < 6; j++) s = s + Lbb[i][j] * ab0[j];
-      blk[i][NZ] = T(0.0) - sw_b * s;
+      blk[i][NV] = T(0.0) - sw_b * s;
       for (int l = 0; l < 4; l++)
         if (!((mask >> l) & 1))
           for (int j = 0; j < 3; j++) blk[i][3 * l + j] = blk[i][3 * l + j] + sw_b * Mt_bl[l][3 * i + j];
     }
-    qr_append(Rf, blk, 6);
+    qr_append<T, NV>(Rf, blk, 6);
     // swing rows (3 per swing leg), appended in blocks of 3
     for (int l = 0; l < 4; l++) {
       if ((mask >> l) & 1) continue;
@@ -1010,10 +1092,10 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
         }
         T s = c1_s[l][i];
         for (int j = 0; j < 6; j++) s = s + Mt_bl[l][3 * j + i] * ab0[j];
-        blk[i][NZ] = T(0.0) - sw_f * s;
+        blk[i][NV] = T(0.0) - sw_f * s;
         for (int j = 0; j < 3; j++) blk[i][3 * l + j] = blk[i][3 * l + j] + sw_f * Mt_ll[l][3 * i + j];
       }
-      qr_append(Rf, blk, 3);
+      qr_append<T, NV>(Rf, blk, 3);
     }
     // keep c1 and Lambda pieces for Vdot: Vdot = xdt' r1 - xdt' Kd xdt, r1 = Lambda y_t + c1
     // evaluated after the solve; stash what is needed in blk-independent storage
@@ -1034,28 +1116,30 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       }
       T s = T(0.0);
       for (int j = 0; j < 6; j++) s = s + Lx_b[j] * ab0[j];
-      blk[0][NZ] = s;
+      blk[0][NV] = s;
       for (int l = 0; l < 4; l++)
         if (!((mask >> l) & 1))
           for (int i = 0; i < 3; i++) blk[0][3 * l + i] = blk[0][3 * l + i] + Lx_s[l][i];
     }
   }
   T vdot_row[NZ + 1];
-  for (int c = 0; c <= NZ; c++) vdot_row[c] = (KIND != KIND_ID) ? blk[0][c] : T(0.0);
+  for (int c = 0; c < NZ; c++) vdot_row[c] = (KIND == KIND_MPTC || KIND == KIND_PC) ? blk[0][c] : T(0.0);
+  vdot_row[NZ] = (KIND == KIND_MPTC || KIND == KIND_PC) ? blk[0][NV] : T(0.0);
 
   // ---- level-2 rows: eps (Tm z + t0)
   for (int h = 0; h < 2; h++) {
     for (int i = 0; i < 6; i++) {
       for (int c = 0; c < NZ; c++) blk[i][c] = eps * Tm[6 * h + i][c];
-      blk[i][NZ] = T(0.0) - eps * Tm[6 * h + i][NZ];
+      for (int c = NZ; c < NV; c++) blk[i][c] = T(0.0);
+      blk[i][NV] = T(0.0) - eps * Tm[6 * h + i][NV];
     }
-    qr_append(Rf, blk, 6);
+    qr_append<T, NV>(Rf, blk, 6);
   }
   // ---- unconstrained minimiser and J = R^-1
-  T z[NZ], Jm[NZ][NZ];
+  T z[NV], Jm[NV][NV];
   {
     T rmax = T(0.0), rmin = T(0.0);
-    for (int i = 0; i < NZ; i++) {
+    for (int i = 0; i < NV; i++) {
       T a = wabs(Rf[i][i]);
       if (i == 0 || a > rmax) rmax = a;
       if (i == 0 || a < rmin) rmin = a;
@@ -1068,13 +1152,13 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     *iters_out = 0;
     return status;
   }
-  for (int k = NZ - 1; k >= 0; k--) {
-    T s = Rf[k][NZ];
-    for (int j = k + 1; j < NZ; j++) s = s - Rf[k][j] * z[j];
+  for (int k = NV - 1; k >= 0; k--) {
+    T s = Rf[k][NV];
+    for (int j = k + 1; j < NV; j++) s = s - Rf[k][j] * z[j];
     z[k] = s / Rf[k][k];
   }
-  for (int c = 0; c < NZ; c++)
-    for (int k = NZ - 1; k >= 0; k--) {
+  for (int c = 0; c < NV; c++)
+    for (int k = NV - 1; k >= 0; k--) {
       if (k > c) { Jm[k][c] = T(0.0); continue; }
       T s = (k == c) ? T(1.0) : T(0.0);
       for (int j = k + 1; j <= c; j++) s = s - Rf[k][j] * Jm[j][c];
@@ -1086,7 +1170,9 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     T s = sqrt(T(1.0) + mu * mu);
     C.inv_s = T(1.0) / s;
     C.mu_n = mu * C.inv_s;
-    C.Trow = Tm;
+    C.Trow = &Tm[0][0];
+    C.tstride = NV + 1;
+    C.clfrow = nullptr;
     C.tau_max = T(P.tau_max);
     C.mask = mask;
     C.pcrow = nullptr;
@@ -1115,14 +1201,18 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       elig |= (1ull << PC_ROW);
     }
   }
+  if (KIND == KIND_CLF) {
+    C.clfrow = clfrow;
+    elig |= (1ull << CLF_ROW);
+  }
   int iters = 0;
-  int st = gi_solve(Jm, z, C, elig, &iters);
+  int st = gi_solve<T, NV>(Jm, z, C, elig, &iters);
   *iters_out = iters;
   if (st != ST_OK) status = st;
   // ---- outputs
   T tauc[12];
   for (int i = 0; i < 12; i++) {
-    T s = Tm[i][NZ];
+    T s = Tm[i][NV];
     for (int c = 0; c < NZ; c++) s = s + Tm[i][c] * z[c];
     tauc[i] = s;
   }
@@ -1136,7 +1226,18 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       if (a > res) res = a;
       if (b > res) res = b;
     }
-  if (KIND != KIND_ID) {
+  if (KIND == KIND_CLF) {
+    // Vdot = 2 eta'PF eta + 2 eta'PG (J vd + Jdv - xdd_nom)   (clf_controller.py:230)
+    T s = clf_c0;
+    for (int i = 0; i < 6; i++) {
+      T ab = ab0[i];
+      for (int c = 0; c < NZ; c++) ab = ab + B[i][c] * z[c];
+      s = s + clf_gb[i] * ab;
+    }
+    for (int l = 0; l < 4; l++)
+      for (int i = 0; i < 3; i++) s = s + clf_gs[l][i] * z[3 * l + i];
+    out_met(0, met_V); out_met(1, met_err); out_met(2, T(0.0)); out_met(3, s);
+  } else if (KIND != KIND_ID) {
     T s = vdot_row[NZ];
     for (int c = 0; c < NZ; c++) s = s + vdot_row[c] * z[c];
     met_Vdot = met_Vdot + s;

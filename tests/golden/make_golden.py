@@ -15,7 +15,7 @@ from quadruped_drake_amd import workloads  # noqa
 
 CASES = [("cfg2_id", 2, "id", 48), ("cfg3_mptc", 3, "mptc", 48), ("cfg3_id", 3, "id", 32),
          ("cfg4_anymal_mptc", 4, "mptc", 48), ("cfg5_rand_mptc", 5, "mptc", 48), ("cfg3_pc", 3, "pc", 64),
-         ("cfg2_pc", 2, "pc", 32)]
+         ("cfg2_pc", 2, "pc", 32), ("cfg3_clf", 3, "clf", 48), ("cfg2_clf", 2, "clf", 32)]
 
 for name, cfg, kind, n in CASES:
     b = workloads.make_batch(cfg, n=n)
@@ -31,7 +31,7 @@ for name, cfg, kind, n in CASES:
 # all 16 contact masks on one state set, both laws
 b = workloads.make_batch(3, n=16)
 m = orc.model("mini_cheetah")
-for kind in ("id", "mptc", "pc"):
+for kind in ("id", "mptc", "pc", "clf"):
     mk = np.arange(16, dtype=np.uint8)
     tau, met, st = orc.step_batch(kind, m, orc.params(kind), b["q"], b["v"], b["targets"], mk)
     np.savez_compressed(os.path.join(HERE, "masks16_%s.npz" % kind), model="mini_cheetah", kind=kind, q=b["q"],

@@ -42,7 +42,7 @@ def run(kind, flat, q, v, targets, mask, mu=None, mass_scale=None, params12=None
     pp = None if params12 is None else np.ascontiguousarray(params12, dtype=np.float64)
     qp = None if q_perm is None else np.ascontiguousarray(q_perm, dtype=np.int32)
     ap = None if act_perm is None else np.ascontiguousarray(act_perm, dtype=np.int32)
-    k = 0 if kind in (0, "id", "ID") else (2 if kind in (2, "pc", "PC") else 1)
+    k = {"id": 0, "mptc": 1, "pc": 2, "clf": 3}[kind.lower()] if isinstance(kind, str) else int(kind)
     fn = lib().host_quad_batch if quad else lib().host_tick_batch
     rc = fn(k, _p(flat), _p(pp), qp.ctypes.data_as(_ip) if qp is not None else None,
                                ap.ctypes.data_as(_ip) if ap is not None else None, n, n, _p(q), _p(v),
@@ -60,7 +60,7 @@ def count(kind, flat, q, v, targets, mask, mu=None, mass_scale=None):
     out = np.zeros(6)
     mu = None if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
     ms = None if mass_scale is None else np.ascontiguousarray(mass_scale, dtype=np.float64)
-    k = 0 if kind in (0, "id", "ID") else (2 if kind in (2, "pc", "PC") else 1)
+    k = {"id": 0, "mptc": 1, "pc": 2, "clf": 3}[kind.lower()] if isinstance(kind, str) else int(kind)
     rc = lib().host_tick_count(k, _p(flat), None, n, n, _p(q), _p(v), _p(targets),
                                mask.ctypes.data_as(C.POINTER(C.c_ubyte)), _p(mu), _p(ms), _p(out))
     assert rc == 0

@@ -36,6 +36,7 @@ def test_params_default_matches_reference_literals():
     assert (p.Kp_body_p, p.Kd_body_p, p.Kp_foot, p.Kd_foot, p.w_body, p.w_foot, p.mu) == (100.0, 10.0, 200.0, 20.0, 10.0, 1.0, 0.7)
     assert np.isinf(p.tau_max)
     assert l.wbc_params_default(2, C.byref(p)) == 0 and p.Kp_foot == 200.0     # PC uses the MPTC gains (pc_controller.py:69-81)
+    assert l.wbc_params_default(3, C.byref(p)) == 0 and p.Kp_body_p == 500.0   # CLF derives from IDController
     assert l.wbc_params_default(7, C.byref(p)) < 0
     assert b"bad argument" in l.wbc_last_error()
 

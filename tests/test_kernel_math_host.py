@@ -16,7 +16,7 @@ def rel_err(tau, tau_o):
     return np.abs(tau - tau_o).max(0) / np.maximum(np.abs(tau_o).max(0), 1e-3)
 
 
-@pytest.mark.parametrize("cfg,kind", [(2, "id"), (3, "mptc"), (3, "id"), (2, "mptc"), (4, "mptc"), (5, "mptc"), (3, "pc"), (2, "pc")])
+@pytest.mark.parametrize("cfg,kind", [(2, "id"), (3, "mptc"), (3, "id"), (2, "mptc"), (4, "mptc"), (5, "mptc"), (3, "pc"), (2, "pc"), (3, "clf"), (2, "clf"), (4, "clf")])
 def test_host_kernel_math_matches_oracle(cfg, kind):
     b = workloads.make_batch(cfg, n=192)
     t = orc.load_model_json(b["model"])
@@ -34,7 +34,7 @@ def test_all_contact_modes_and_params():
     t = orc.load_model_json("mini_cheetah"); m = orc.model("mini_cheetah")
     for mask in range(16):
         mk = np.full(16, mask, np.uint8)
-        for kind in ("id", "mptc"):
+        for kind in ("id", "mptc", "pc", "clf"):
             p = orc.params(kind)
             tau_o, met_o, st_o = orc.step_batch(kind, m, p, b["q"], b["v"], b["targets"], mk)
             tau, met, st, it = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], mk)

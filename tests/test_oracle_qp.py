@@ -211,3 +211,34 @@ def test_pc_law_literal_qp():
         else:
             assert np.allclose(tau, t_m, atol=1e-7)    # inactive: identical to MPTC
     assert found
+
+
+def test_clf_law_literal_qp():
+    """clf_controller.py: closed-form CARE == scipy, literal cost == square-root form, CLF row holds,
+    delta = max(0, row) and an independent scipy solve of the literal QP agrees."""
+    import ctypes as C
+    from scipy.linalg import solve_continuous_are
+    for qp_, qd_, r_ in ((5000.0, 200.0, 1.0), (200.0, 20.0, 1.0), (3.0, 0.7, 2.5)):
+        a, bb, c = C.c_double(), C.c_double(), C.c_double()
+        orc.lib().orc_clf_care(C.c_double(qp_), C.c_double(qd_), C.c_double(r_), C.byref(a), C.byref(bb), C.byref(c))
+        P = solve_continuous_are(np.array([[0, 1], [0, 0.0]]), np.array([[0], [1.0]]), np.diag([qp_, qd_]), np.array([[r_]]))
+        assert np.allclose(P, [[a.value, bb.value], [bb.value, c.value]], rtol=1e-10)
+    b, q, v, tg, ct = tick_inputs(3, 4)
+    m = orc.model(b["model"]); p = orc.params("clf")
+    tau, met, st, qp = orc.control_law("clf", m, p, q, v, tg, ct, want_qp=True)
+    assert st == 0
+    n, nc = qp["n"], qp["nc"]
+    assert n == 31 + 3 * nc and qp["mi"] == 4 * nc + 1
+    x = qp["x"]
+    assert np.allclose(qp["Als"].T @ qp["Als"], qp["Q"], atol=1e-9 * np.abs(qp["Q"]).max())
+    assert np.allclose(-qp["Als"].T @ qp["bls"], qp["c"], atol=1e-9 * (1 + np.abs(qp["c"]).max()))
+    assert (qp["Ain"] @ x - qp["bin"]).max() < 1e-8 and np.abs(qp["Aeq"] @ x - qp["beq"]).max() < 1e-9
+    row = qp["Ain"][4 * nc]
+    h = row[:-1] @ x[:-1] - qp["bin"][4 * nc]
+    assert abs(x[-1] - max(0.0, h)) < 1e-7 * (1 + abs(h))
+    assert met[0] > 0
+    p.tiebreak_eps2 = 1e-4
+    tau, met, st, qp = orc.control_law("clf", m, p, q, v, tg, ct, want_qp=True)
+    D = np.diag(((np.arange(n) >= 18) & (np.arange(n) < n - 1)).astype(float))
+    xs = scipy_qp(qp["Q"] + p.tiebreak_eps2 * D, qp["c"], qp["Aeq"], qp["beq"], qp["Ain"], qp["bin"])
+    assert np.allclose(qp["x"], xs, atol=5e-5 * (1 + np.abs(xs).max())), np.abs(qp["x"] - xs).max()

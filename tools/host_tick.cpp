@@ -45,6 +45,7 @@ static int run_one(int kind, const wbc::ModelC& m, const wbc::ParamsC& P, int i,
   auto om = [&](int k, T x) { if (met) met[(size_t)k * stride + i] = val<T>(x); };
   if (kind == wbc::KIND_ID) return wbc::tick<T, wbc::KIND_ID>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
   if (kind == wbc::KIND_PC) return wbc::tick<T, wbc::KIND_PC>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
+  if (kind == wbc::KIND_CLF) return wbc::tick<T, wbc::KIND_CLF>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
   return wbc::tick<T, wbc::KIND_MPTC>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
 }
 
@@ -97,6 +98,7 @@ int host_tick_count(int kind, const double* flat215, const double* params12, int
     Cnt muv(mu ? mu[i] : P.mu), msv(mass_scale ? mass_scale[i] : 1.0);
     if (kind == wbc::KIND_ID) wbc::tick<Cnt, wbc::KIND_ID>(m, P, in, mask[i], muv, msv, ot, om, &it);
     else if (kind == wbc::KIND_PC) wbc::tick<Cnt, wbc::KIND_PC>(m, P, in, mask[i], muv, msv, ot, om, &it);
+    else if (kind == wbc::KIND_CLF) wbc::tick<Cnt, wbc::KIND_CLF>(m, P, in, mask[i], muv, msv, ot, om, &it);
     else wbc::tick<Cnt, wbc::KIND_MPTC>(m, P, in, mask[i], muv, msv, ot, om, &it);
   }
   (void)tau; (void)met;
