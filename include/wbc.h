@@ -36,6 +36,7 @@
 #ifndef WBC_H
 #define WBC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -133,6 +134,40 @@ int wbc_set_variant(wbc_handle h, int variant);
 
 /* Kernel resource report for the handle's kind: registers, scratch bytes/lane, LDS bytes. */
 int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads);
+
+/* ------------------------------------------------------------------------------------------
+ * Callers of the path: trunk-trajectory wire format and target lookup.
+ *
+ * wbc_trunk_state mirrors lcm_types/trunk_state_t.lcm:3-49; the wire format is the 549-byte
+ * big-endian LCM encoding of lcm_types/trunklcm/trunk_state_t.py:50-121 (8-byte fingerprint, then
+ * the fields in declaration order).  Feet are [lf rf lh rh].  Host-side, no GPU needed. */
+#define WBC_TRUNK_STATE_BYTES 549
+typedef struct {
+  double timestamp;
+  uint8_t finished;
+  double base_p[3], base_pd[3], base_pdd[3], base_rpy[3], base_rpyd[3], base_rpydd[3];
+  double foot_p[4][3], foot_pd[4][3], foot_pdd[4][3];
+  uint8_t contact[4];
+  double foot_f[4][3];
+} wbc_trunk_state;
+
+/* 0 on success; -1 short buffer, -3 fingerprint mismatch ("Decode error", trunk_state_t.py:87-88). */
+int wbc_trunk_state_decode(const uint8_t* buf, size_t len, wbc_trunk_state* out);
+/* planners/towr.py:111-148: message -> the 54 target rows + contact mask of wbc_step. */
+int wbc_trunk_state_to_targets(const wbc_trunk_state* s, double* targets54, uint8_t* contact_mask);
+
+/* A stored trunk trajectory on the device and the per-tick lookup of planners/towr.py:92-106:
+ * t < wait_time -> the standing targets (planners/simple.py:39-85), otherwise the sample whose
+ * timestamp is nearest to t - wait_time (first index on ties: numpy argmin).  `timestamps` must be
+ * non-decreasing; `targets` is [K][54] (one row per sample), `masks` [K]. */
+typedef struct wbc_traj_s* wbc_traj;
+int wbc_traj_create(int device, int K, const double* timestamps, const double* targets, const uint8_t* masks,
+                    const double* standing_targets54, uint8_t standing_mask, double wait_time, wbc_traj* out);
+int wbc_traj_destroy(wbc_traj t);
+/* time[n] (device): per-instance simulation time.  Writes targets[54][ld] and contact_mask[n]
+ * (device) on `hip_stream` (NULL = default stream).  Asynchronous. */
+int wbc_traj_lookup(wbc_traj t, void* hip_stream, int n, int ld, const double* time, double* targets,
+                    uint8_t* contact_mask);
 
 #ifdef __cplusplus
 }

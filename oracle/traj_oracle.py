@@ -1,0 +1,53 @@
+"""CPU ORACLE (test infrastructure) for the callers of the path: numpy/struct restatements of
+  lcm_types/trunklcm/trunk_state_t.py:83-121  (decode of the 549-byte big-endian message)
+  planners/towr.py:92-148                     (nearest-timestamp lookup and dict unpacking)
+Pinned by fixtures produced with the reference's OWN encoder (tests/golden/make_trunk_state_golden.py).
+"""
+import struct
+
+import numpy as np
+
+FINGERPRINT = struct.pack(">Q", ((0xbd03c56c9649d0b6 << 1) & 0xffffffffffffffff) + (0xbd03c56c9649d0b6 >> 63))
+
+
+def decode(buf):
+    """trunk_state_t.py:83-121"""
+    if buf[:8] != FINGERPRINT:
+        raise ValueError("Decode error")
+    off = 8
+    ts, fin = struct.unpack_from(">db", buf, off); off += 9
+    v = []
+    for _ in range(18):
+        v.append(struct.unpack_from(">3d", buf, off)); off += 24
+    ct = struct.unpack_from(">bbbb", buf, off); off += 4
+    f = []
+    for _ in range(4):
+        f.append(struct.unpack_from(">3d", buf, off)); off += 24
+    assert off == 549
+    names = ["base_p", "base_pd", "base_pdd", "base_rpy", "base_rpyd", "base_rpydd", "lf_p", "rf_p", "lh_p", "rh_p",
+             "lf_pd", "rf_pd", "lh_pd", "rh_pd", "lf_pdd", "rf_pdd", "lh_pdd", "rh_pdd"]
+    d = {n: np.array(x) for n, x in zip(names, v)}
+    d.update(timestamp=ts, finished=bool(fin), contact=[bool(c) for c in ct], foot_f=np.array(f))
+    return d
+
+
+def to_targets(d):
+    """planners/towr.py:111-148 -> 54 rows + mask (order of include/wbc.h)."""
+    t = np.concatenate([d["base_p"], d["base_pd"], d["base_pdd"], d["base_rpy"], d["base_rpyd"], d["base_rpydd"]] +
+                       [np.concatenate([d[f + "_p"], d[f + "_pd"], d[f + "_pdd"]]) for f in ("lf", "rf", "lh", "rh")])
+    mask = sum(1 << i for i, c in enumerate(d["contact"]) if c)
+    return t, mask
+
+
+def lookup(time, timestamps, table, masks, standing, standing_mask, wait_time):
+    """planners/towr.py:92-106 per instance: t < wait_time -> standing; else argmin |ts - (t - wait)|."""
+    time = np.asarray(time, float)
+    ts = np.asarray(timestamps, float)
+    out = np.zeros((54, time.size)); mk = np.zeros(time.size, np.uint8)
+    for i, t in enumerate(time):
+        if t < wait_time or ts.size == 0:
+            out[:, i] = standing; mk[i] = standing_mask
+        else:
+            k = int(np.abs(ts - (t - wait_time)).argmin())
+            out[:, i] = table[k]; mk[i] = masks[k]
+    return out, mk

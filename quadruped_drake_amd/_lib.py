@@ -16,7 +16,8 @@ DEVICE_PTRS, HOST_PTRS = 0, 1
 # every symbol include/wbc.h declares
 SYMBOLS = ["wbc_last_error", "wbc_version", "wbc_params_default", "wbc_create", "wbc_destroy", "wbc_set_stream",
            "wbc_step", "wbc_sync", "wbc_time_steps", "wbc_stats_get", "wbc_stats_reset", "wbc_set_variant",
-           "wbc_kernel_info"]
+           "wbc_kernel_info", "wbc_trunk_state_decode", "wbc_trunk_state_to_targets", "wbc_traj_create",
+           "wbc_traj_destroy", "wbc_traj_lookup"]
 
 
 class WbcModel(C.Structure):
@@ -33,6 +34,14 @@ class WbcStats(C.Structure):
     _fields_ = [("ticks", C.c_double), ("status_nonzero", C.c_double), ("iters_sum", C.c_double),
                 ("tau_abs_sum", C.c_double), ("tau_abs_max", C.c_double), ("err_sum", C.c_double),
                 ("mask_count", C.c_double * 16)]
+
+
+class WbcTrunkState(C.Structure):
+    _fields_ = [("timestamp", C.c_double), ("finished", C.c_uint8),
+                ("base_p", C.c_double * 3), ("base_pd", C.c_double * 3), ("base_pdd", C.c_double * 3),
+                ("base_rpy", C.c_double * 3), ("base_rpyd", C.c_double * 3), ("base_rpydd", C.c_double * 3),
+                ("foot_p", (C.c_double * 3) * 4), ("foot_pd", (C.c_double * 3) * 4), ("foot_pdd", (C.c_double * 3) * 4),
+                ("contact", C.c_uint8 * 4), ("foot_f", (C.c_double * 3) * 4)]
 
 
 class WbcError(RuntimeError):
@@ -64,6 +73,12 @@ def lib():
         l.wbc_stats_reset.argtypes = [C.c_void_p]
         l.wbc_set_variant.argtypes = [C.c_void_p, C.c_int]
         l.wbc_kernel_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 4
+        l.wbc_trunk_state_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(WbcTrunkState)]
+        l.wbc_trunk_state_to_targets.argtypes = [C.POINTER(WbcTrunkState), c_double_p, c_u8_p]
+        l.wbc_traj_create.argtypes = [C.c_int, C.c_int, c_double_p, c_double_p, c_u8_p, c_double_p, C.c_uint8, C.c_double,
+                                      C.POINTER(C.c_void_p)]
+        l.wbc_traj_destroy.argtypes = [C.c_void_p]
+        l.wbc_traj_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         for s in SYMBOLS:
             getattr(l, s)
         _lib = l

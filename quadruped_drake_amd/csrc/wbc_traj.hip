@@ -1,0 +1,157 @@
+// wbc_traj.hip -- callers of the hot path: trunk_state_t wire decode and the
+// device-side nearest-timestamp target lookup of planners/towr.py:92-148.  Byte/index work:
+// bit-exact against the reference's own encoder (tests/golden/trunk_state_*).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/wbc.h"
+
+namespace {
+thread_local char g_terr[256] = "";
+int tfail(const char* what, hipError_t e) { snprintf(g_terr, sizeof g_terr, "%s: %s", what, hipGetErrorString(e)); return -2; }
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return tfail(#x, e_); } while (0)
+
+// lcm_types/trunklcm/trunk_state_t.py:123-133: hash = rotl1(0xbd03c56c9649d0b6)
+constexpr uint64_t kBase = 0xbd03c56c9649d0b6ull;
+constexpr uint64_t kFingerprint = (kBase << 1) + (kBase >> 63);
+
+inline double be_double(const uint8_t* p) {
+  uint64_t u = 0;
+  for (int i = 0; i < 8; i++) u = (u << 8) | p[i];
+  double d;
+  memcpy(&d, &u, 8);
+  return d;
+}
+inline const uint8_t* rd3(const uint8_t* p, double* out) {
+  for (int i = 0; i < 3; i++) out[i] = be_double(p + 8 * i);
+  return p + 24;
+}
+
+// One thread per robot: binary search in the non-decreasing timestamps, nearest sample, first index
+// on ties and among equal timestamps (what np.abs(ts - t).argmin() returns), then a 54-double gather.
+__global__ void traj_lookup_kernel(int n, int ld, int K, double wait_time, const double* __restrict__ time,
+                                   const double* __restrict__ ts, const double* __restrict__ table,
+                                   const uint8_t* __restrict__ masks, const double* __restrict__ standing,
+                                   uint8_t standing_mask, double* __restrict__ targets,
+                                   uint8_t* __restrict__ contact_mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double t = time[i];
+  const double* src;
+  uint8_t mk;
+  if (t < wait_time || K == 0) {
+    src = standing;
+    mk = standing_mask;
+  } else {
+    t -= wait_time;
+    int lo = 0, hi = K;  // first index with ts[idx] >= t
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (ts[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    int c;
+    if (lo == 0) c = 0;
+    else if (lo == K) c = K - 1;
+    else c = (fabs(ts[lo - 1] - t) <= fabs(ts[lo] - t)) ? lo - 1 : lo;
+    while (c > 0 && ts[c - 1] == ts[c]) c--;
+    src = table + (size_t)c * 54;
+    mk = masks[c];
+  }
+  for (int r = 0; r < 54; r++) targets[(size_t)r * ld + i] = src[r];
+  contact_mask[i] = mk;
+}
+}  // namespace
+
+struct wbc_traj_s {
+  int device, K;
+  double wait_time;
+  uint8_t standing_mask;
+  double *d_ts, *d_table, *d_standing;
+  uint8_t* d_masks;
+};
+
+extern "C" {
+
+int wbc_trunk_state_decode(const uint8_t* buf, size_t len, wbc_trunk_state* out) {
+  if (!buf || !out || len < WBC_TRUNK_STATE_BYTES) return -1;
+  uint64_t fp = 0;
+  for (int i = 0; i < 8; i++) fp = (fp << 8) | buf[i];
+  if (fp != kFingerprint) return -3;
+  const uint8_t* p = buf + 8;
+  out->timestamp = be_double(p); p += 8;
+  out->finished = (*p++) != 0;
+  p = rd3(p, out->base_p); p = rd3(p, out->base_pd); p = rd3(p, out->base_pdd);
+  p = rd3(p, out->base_rpy); p = rd3(p, out->base_rpyd); p = rd3(p, out->base_rpydd);
+  for (int f = 0; f < 4; f++) p = rd3(p, out->foot_p[f]);
+  for (int f = 0; f < 4; f++) p = rd3(p, out->foot_pd[f]);
+  for (int f = 0; f < 4; f++) p = rd3(p, out->foot_pdd[f]);
+  for (int f = 0; f < 4; f++) out->contact[f] = (*p++) != 0;
+  for (int f = 0; f < 4; f++) p = rd3(p, out->foot_f[f]);
+  return (p - buf) == WBC_TRUNK_STATE_BYTES ? 0 : -1;
+}
+
+int wbc_trunk_state_to_targets(const wbc_trunk_state* s, double* t, uint8_t* contact_mask) {
+  if (!s || !t || !contact_mask) return -1;
+  const double* body[6] = {s->base_p, s->base_pd, s->base_pdd, s->base_rpy, s->base_rpyd, s->base_rpydd};
+  for (int k = 0; k < 6; k++) for (int i = 0; i < 3; i++) t[3 * k + i] = body[k][i];
+  uint8_t m = 0;
+  for (int f = 0; f < 4; f++) {
+    for (int i = 0; i < 3; i++) {
+      t[18 + 9 * f + i] = s->foot_p[f][i];
+      t[21 + 9 * f + i] = s->foot_pd[f][i];
+      t[24 + 9 * f + i] = s->foot_pdd[f][i];
+    }
+    if (s->contact[f]) m |= (uint8_t)(1u << f);
+  }
+  *contact_mask = m;
+  return 0;
+}
+
+int wbc_traj_create(int device, int K, const double* timestamps, const double* targets, const uint8_t* masks,
+                    const double* standing_targets54, uint8_t standing_mask, double wait_time, wbc_traj* out) {
+  if (!out || K < 0 || (K > 0 && (!timestamps || !targets || !masks)) || !standing_targets54) return -1;
+  for (int i = 1; i < K; i++)
+    if (!(timestamps[i] >= timestamps[i - 1])) return -1;  // must be non-decreasing
+  HIP_TRY(hipSetDevice(device));
+  wbc_traj t = new wbc_traj_s();
+  memset(t, 0, sizeof *t);
+  t->device = device; t->K = K; t->wait_time = wait_time; t->standing_mask = standing_mask;
+  const size_t kk = K > 0 ? K : 1;
+  HIP_TRY(hipMalloc(&t->d_ts, kk * 8));
+  HIP_TRY(hipMalloc(&t->d_table, kk * 54 * 8));
+  HIP_TRY(hipMalloc(&t->d_masks, kk));
+  HIP_TRY(hipMalloc(&t->d_standing, 54 * 8));
+  if (K > 0) {
+    HIP_TRY(hipMemcpy(t->d_ts, timestamps, (size_t)K * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t->d_table, targets, (size_t)K * 54 * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(t->d_masks, masks, (size_t)K, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMemcpy(t->d_standing, standing_targets54, 54 * 8, hipMemcpyHostToDevice));
+  *out = t;
+  return 0;
+}
+
+int wbc_traj_destroy(wbc_traj t) {
+  if (!t) return 0;
+  (void)hipSetDevice(t->device);
+  (void)hipFree(t->d_ts); (void)hipFree(t->d_table); (void)hipFree(t->d_masks); (void)hipFree(t->d_standing);
+  delete t;
+  return 0;
+}
+
+int wbc_traj_lookup(wbc_traj t, void* hip_stream, int n, int ld, const double* time, double* targets,
+                    uint8_t* contact_mask) {
+  if (!t || n < 0 || (n > 0 && (ld < n || !time || !targets || !contact_mask))) return -1;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(t->device));
+  hipLaunchKernelGGL(traj_lookup_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, n, ld, t->K,
+                     t->wait_time, time, t->d_ts, t->d_table, t->d_masks, t->d_standing, t->standing_mask, targets,
+                     contact_mask);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"
