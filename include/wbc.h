@@ -79,6 +79,7 @@ typedef struct {
 } wbc_params;
 
 typedef struct wbc_handle_s* wbc_handle;
+typedef struct wbc_traj_s* wbc_traj; /* stored trunk trajectory, see the end of this header */
 
 /* End-of-rollout statistics accumulated on the device by wbc_step (one small vector per GPU;
  * reduced across GPUs by the host with one RCCL all-reduce). */
@@ -127,6 +128,25 @@ int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, cons
 int wbc_stats_get(wbc_handle h, wbc_stats* out);
 int wbc_stats_reset(wbc_handle h);
 
+/* Closed-loop rollouts.  If set (device pointer, [18][ld], same ld as wbc_step),
+ * every wbc_step also writes the generalized accelerations vd of its QP solution (rows in the
+ * order of v: w_WB-dot, v_WBo-dot, 12 joint accelerations in the caller's joint order).  NULL disables. */
+int wbc_set_vdot_output(wbc_handle h, double* vdot);
+
+/* Semi-implicit Euler on the reference's state conventions, in place on device arrays:
+ *   v+ = v + dt vd ;  p+ = p + dt v_lin+ ;  quat+ = exp(dt/2 w+) (x) quat (world-frame w), renormalised ;
+ *   joints+ = joints + dt qd+.   A simplified stand-in for MultibodyPlant(time_step=dt) (simulate.py:38):
+ * contacts are whatever the QP's contact rows imply, there is no collision solver.  Asynchronous. */
+int wbc_integrate(wbc_handle h, int n, int ld, double dt, double* q, double* v, const double* vdot);
+
+/* `steps` closed-loop ticks entirely on the device: targets/contact from `traj` at time[i]
+ * (wbc_traj_lookup), wbc_step, wbc_integrate, time += dt.  q, v, time, targets, contact_mask, tau,
+ * vdot are device buffers ([..][ld]); metrics/status may be NULL.  Statistics accumulate in the
+ * handle (wbc_stats_get).  Asynchronous on the handle's stream. */
+int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld, double* q, double* v,
+                double* time, double* targets, uint8_t* contact_mask, const double* mu,
+                const double* mass_scale, double* tau, double* metrics, int32_t* status, double* vdot);
+
 /* Kernel variant: 0 = auto (default), 1 = lane-per-robot, 2 = quad-per-robot (4 lanes = 4 legs).
  * Both compute the same tick; auto picks quad unless the optional torque box is enabled or the
  * kind is WBC_KIND_CLF (13 reduced variables: lane kernel only). */
@@ -160,7 +180,6 @@ int wbc_trunk_state_to_targets(const wbc_trunk_state* s, double* targets54, uint
  * t < wait_time -> the standing targets (planners/simple.py:39-85), otherwise the sample whose
  * timestamp is nearest to t - wait_time (first index on ties: numpy argmin).  `timestamps` must be
  * non-decreasing; `targets` is [K][54] (one row per sample), `masks` [K]. */
-typedef struct wbc_traj_s* wbc_traj;
 int wbc_traj_create(int device, int K, const double* timestamps, const double* targets, const uint8_t* masks,
                     const double* standing_targets54, uint8_t standing_mask, double wait_time, wbc_traj* out);
 int wbc_traj_destroy(wbc_traj t);

@@ -51,3 +51,21 @@ def lookup(time, timestamps, table, masks, standing, standing_mask, wait_time):
             k = int(np.abs(ts - (t - wait_time)).argmin())
             out[:, i] = table[k]; mk[i] = masks[k]
     return out, mk
+
+
+def integrate(q, v, vd, dt):
+    """Semi-implicit Euler in the reference's coordinates (include/wbc.h wbc_integrate): numpy restatement.
+    q [19, N], v [18, N], vd [18, N] -> (q+, v+)."""
+    q = np.array(q, float); v = np.array(v, float) + dt * np.asarray(vd, float)
+    w = v[0:3]
+    wn = np.sqrt((w * w).sum(0))
+    ang = 0.5 * wn * dt
+    sc = np.where(wn > 0, np.sin(ang) / np.where(wn > 0, wn, 1.0), 0.0)
+    dw = np.where(wn > 0, np.cos(ang), 1.0); dx, dy, dz = sc * w[0], sc * w[1], sc * w[2]
+    w1, x1, y1, z1 = q[0].copy(), q[1].copy(), q[2].copy(), q[3].copy()
+    qq = np.stack([dw * w1 - dx * x1 - dy * y1 - dz * z1, dw * x1 + dx * w1 + dy * z1 - dz * y1,
+                   dw * y1 - dx * z1 + dy * w1 + dz * x1, dw * z1 + dx * y1 - dy * x1 + dz * w1])
+    q[0:4] = qq / np.sqrt((qq * qq).sum(0))
+    q[4:7] += dt * v[3:6]
+    q[7:] += dt * v[6:]
+    return q, v

@@ -170,6 +170,32 @@ class BatchedController:
             _lib.check(self._L.wbc_stats_reset(self._h))
         return d
 
+    # -- closed-loop rollouts ---------------------------------------------------
+    def set_vdot_output(self, vdot):
+        """CUDA float64 [18, N] tensor that every step() fills with the QP's generalized accelerations (None: off)."""
+        self._vdot = vdot
+        _lib.check(self._L.wbc_set_vdot_output(self._h, C.c_void_p(vdot.data_ptr()) if vdot is not None else None))
+
+    def integrate(self, q, v, vdot, dt):
+        """Semi-implicit Euler step, in place on q [19, N] and v [18, N]."""
+        n = int(q.shape[1])
+        _lib.check(self._L.wbc_integrate(self._h, n, n, float(dt), C.c_void_p(q.data_ptr()), C.c_void_p(v.data_ptr()),
+                                         C.c_void_p(vdot.data_ptr())))
+
+    def rollout(self, traj, steps, dt, q, v, time, mu=None, mass_scale=None):
+        """`steps` closed-loop ticks on the device: lookup(traj, time) -> step -> integrate.  Updates q, v, time in
+        place; returns the last (tau, metrics, status, targets, mask)."""
+        import torch
+        n = int(q.shape[1]); dev = q.device
+        tg = torch.empty((54, n), dtype=torch.float64, device=dev); mk = torch.empty((n,), dtype=torch.uint8, device=dev)
+        tau = torch.empty((12, n), dtype=torch.float64, device=dev); met = torch.empty((4, n), dtype=torch.float64, device=dev)
+        st = torch.empty((n,), dtype=torch.int32, device=dev); vd = torch.empty((18, n), dtype=torch.float64, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(self._L.wbc_rollout(self._h, traj._h, int(steps), float(dt), n, n, p(q), p(v), p(time), p(tg), p(mk),
+                                       p(mu), p(mass_scale), p(tau), p(met), p(st), p(vd)))
+        self._keep = (tg, mk, tau, met, st, vd, mu, mass_scale)
+        return tau, met, st, tg, mk
+
     def set_variant(self, variant):
         """0 = auto, 1 = lane-per-robot kernel, 2 = quad-per-robot kernel."""
         v = {"auto": 0, "lane": 1, "quad": 2}.get(variant, variant)

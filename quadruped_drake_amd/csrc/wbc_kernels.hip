@@ -63,7 +63,7 @@ wbc_tick_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
                 const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
                 const uint8_t* __restrict__ mask, const double* __restrict__ mu,
                 const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
-                int32_t* __restrict__ status, StatsDev* __restrict__ stats) {
+                int32_t* __restrict__ status, StatsDev* __restrict__ stats, double* __restrict__ vdot) {
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   const bool live = i < n;
   const int ii = live ? i : (n - 1);  // tail lanes recompute the last robot, stores are masked
@@ -80,7 +80,8 @@ wbc_tick_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
     tsum += fabs(x);
     tmax = fmax(tmax, fabs(x));
   };
-  auto om = [&](int k, double x) {
+  auto om = [&](int k, double x) {   // rows 0..3: metrics, rows 4..21: generalized accelerations
+    if (k >= 4) { if (live && vdot) vdot[(size_t)(k - 4) * ld + ii] = x; return; }
     if (live && met) met[(size_t)k * ld + ii] = x;
     if (k == 1) errv = x;
   };
@@ -242,7 +243,7 @@ wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
                 const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
                 const uint8_t* __restrict__ mask, const double* __restrict__ mu,
                 const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
-                int32_t* __restrict__ status, StatsDev* __restrict__ stats) {
+                int32_t* __restrict__ status, StatsDev* __restrict__ stats, double* __restrict__ vdot) {
 #if WBC_STAGE_IN_LDS
   __shared__ double arena[KIN_DOUBLES + STAGE_DOUBLES + SHQ_DOUBLES];
   StageLds stage(arena + KIN_DOUBLES + threadIdx.x);
@@ -306,7 +307,11 @@ wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
     tmax = fmax(tmax, fabs(x));
   };
   const bool lead = qo.l == 0;
-  auto om = [&](int k, double x) {
+  auto om = [&](int k, double x) {   // rows 0..3: metrics (lead lane), rows 4..21: generalized accelerations
+    if (k >= 4) {
+      if (live && vdot && (k >= 10 || lead)) vdot[(size_t)(k - 4) * ld + ii] = x;   // base rows are replicated: lead writes
+      return;
+    }
     if (live && lead && met) met[(size_t)k * ld + ii] = x;
     if (k == 1) errv = x;
   };
@@ -336,6 +341,41 @@ wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
   }
 }
 
+// ---------------------------------------------------------------- forward step
+// Semi-implicit Euler in the reference's coordinates: v = [w_WB (world); v_WBo (world); qd].
+__global__ void wbc_integrate_kernel(int n, int ld, double dt, double* __restrict__ q, double* __restrict__ v,
+                                     const double* __restrict__ vd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double vn[18];
+  for (int r = 0; r < 18; r++) {
+    vn[r] = v[(size_t)r * ld + i] + dt * vd[(size_t)r * ld + i];
+    v[(size_t)r * ld + i] = vn[r];
+  }
+  // orientation: q+ = exp(dt/2 w) (x) q, w in the world frame
+  const double wn = sqrt(vn[0] * vn[0] + vn[1] * vn[1] + vn[2] * vn[2]);
+  const double ang = 0.5 * wn * dt;
+  double dw = 1.0, dx = 0.0, dy = 0.0, dz = 0.0;
+  if (wn > 0.0) {
+    const double sc = sin(ang) / wn;
+    dw = cos(ang); dx = sc * vn[0]; dy = sc * vn[1]; dz = sc * vn[2];
+  }
+  const double w1 = q[i], x1 = q[(size_t)ld + i], y1 = q[(size_t)2 * ld + i], z1 = q[(size_t)3 * ld + i];
+  double qw = dw * w1 - dx * x1 - dy * y1 - dz * z1;
+  double qx = dw * x1 + dx * w1 + dy * z1 - dz * y1;
+  double qy = dw * y1 - dx * z1 + dy * w1 + dz * x1;
+  double qz = dw * z1 + dx * y1 - dy * x1 + dz * w1;
+  const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+  q[i] = qw * inv; q[(size_t)ld + i] = qx * inv; q[(size_t)2 * ld + i] = qy * inv; q[(size_t)3 * ld + i] = qz * inv;
+  for (int r = 0; r < 3; r++) q[(size_t)(4 + r) * ld + i] += dt * vn[3 + r];
+  for (int r = 0; r < 12; r++) q[(size_t)(7 + r) * ld + i] += dt * vn[6 + r];
+}
+
+__global__ void wbc_advance_time_kernel(int n, double dt, double* __restrict__ time) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) time[i] += dt;
+}
+
 }  // namespace
 
 struct wbc_handle_s {
@@ -349,6 +389,7 @@ struct wbc_handle_s {
   StatsDev* d_stats;
   hipEvent_t ev0, ev1;
   // staging buffers for WBC_HOST_PTRS
+  double* d_vdot;  // optional [18][ld] output of the generalized accelerations (wbc_set_vdot_output)
   double *s_q, *s_v, *s_tg, *s_mu, *s_ms, *s_tau, *s_met;
   uint8_t* s_mask;
   int32_t* s_status;
@@ -463,15 +504,15 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
     switch (h->kind) {                                                                                       \
       case WBC_KIND_ID:                                                                                      \
         hipLaunchKernelGGL(KERNEL<wbc::KIND_ID>, GRID, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg, \
-                           mask, mu, ms, tau, met, status, d_stats);                                         \
+                           mask, mu, ms, tau, met, status, d_stats, h->d_vdot);                                         \
         break;                                                                                               \
       case WBC_KIND_MPTC:                                                                                    \
         hipLaunchKernelGGL(KERNEL<wbc::KIND_MPTC>, GRID, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v,   \
-                           tg, mask, mu, ms, tau, met, status, d_stats);                                     \
+                           tg, mask, mu, ms, tau, met, status, d_stats, h->d_vdot);                                     \
         break;                                                                                               \
       default:                                                                                               \
         hipLaunchKernelGGL(KERNEL<wbc::KIND_PC>, GRID, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg, \
-                           mask, mu, ms, tau, met, status, d_stats);                                         \
+                           mask, mu, ms, tau, met, status, d_stats, h->d_vdot);                                         \
     }                                                                                                        \
   } while (0)
   if (quad) {
@@ -480,7 +521,7 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
   } else if (h->kind == WBC_KIND_CLF) {
     dim3 grid((n + BLOCK - 1) / BLOCK);
     hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_CLF>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg,
-                       mask, mu, ms, tau, met, status, d_stats);
+                       mask, mu, ms, tau, met, status, d_stats, h->d_vdot);
   } else {
     dim3 grid((n + BLOCK - 1) / BLOCK);
     WBC_LAUNCH(wbc_tick_kernel, grid);
@@ -583,6 +624,48 @@ int wbc_debug_stamps(unsigned long long* out, int nblocks) {
   return 0;
 }
 #endif
+
+int wbc_set_vdot_output(wbc_handle h, double* vdot) {
+  if (!h) return misuse("wbc_set_vdot_output: null handle");
+  if (vdot && (h->flags & WBC_HOST_PTRS)) return misuse("wbc_set_vdot_output: needs a WBC_DEVICE_PTRS handle");
+  h->d_vdot = vdot;
+  return 0;
+}
+
+int wbc_integrate(wbc_handle h, int n, int ld, double dt, double* q, double* v, const double* vdot) {
+  if (!h) return misuse("wbc_integrate: null handle");
+  if (n < 0 || (n > 0 && (ld < n || !q || !v || !vdot))) return misuse("wbc_integrate: bad arguments");
+  if (h->flags & WBC_HOST_PTRS) return misuse("wbc_integrate: needs a WBC_DEVICE_PTRS handle");
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(h->device));
+  hipLaunchKernelGGL(wbc_integrate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, ld, dt, q, v, vdot);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld, double* q, double* v,
+                double* time, double* targets, uint8_t* contact_mask, const double* mu,
+                const double* mass_scale, double* tau, double* metrics, int32_t* status, double* vdot) {
+  if (!h || !traj) return misuse("wbc_rollout: null handle");
+  if (steps < 0 || !time || !vdot) return misuse("wbc_rollout: steps >= 0, time and vdot are required");
+  int rc = check_step_args(h, n, ld, q, v, targets, contact_mask, tau);
+  if (rc) return rc;
+  if (h->flags & WBC_HOST_PTRS) return misuse("wbc_rollout: needs a WBC_DEVICE_PTRS handle");
+  double* saved = h->d_vdot;
+  h->d_vdot = vdot;
+  for (int s = 0; s < steps && rc == 0; s++) {
+    rc = wbc_traj_lookup(traj, (void*)h->stream, n, ld, time, targets, contact_mask);
+    if (rc) { snprintf(g_err, sizeof g_err, "wbc_rollout: wbc_traj_lookup failed (%d)", rc); break; }
+    rc = launch(h, n, ld, q, v, targets, contact_mask, mu, mass_scale, tau, metrics, status);
+    if (rc) break;
+    hipLaunchKernelGGL(wbc_integrate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, ld, dt, q, v, vdot);
+    hipLaunchKernelGGL(wbc_advance_time_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, dt, time);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) rc = fail("wbc_rollout launch", e);
+  }
+  h->d_vdot = saved;
+  return rc;
+}
 
 int wbc_set_variant(wbc_handle h, int variant) {
   if (!h) return misuse("wbc_set_variant: null handle");

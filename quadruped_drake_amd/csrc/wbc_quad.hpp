@@ -925,6 +925,13 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
       for (int j = 0; j < 3; j++) s += (ct ? -st.get(ST_JL + 3 * j + i) : st.get(ST_PM + 3 * i + j)) * zl[j];
       out_tau(m.act_inv[3 * l + i], (status == ST_SINGULAR) ? 0.0 : s);
     }
+    // generalized accelerations of the QP solution (rows 4..21 of out_met; see wbc_tick.hpp)
+    for (int i = 0; i < 6; i++) out_met(4 + i, ab[i]);
+    double t[3], y[3];
+    cross(ab, rf, t);
+    for (int i = 0; i < 3; i++) y[i] = (ct ? bc[i] : zl[i]) - (ab[3 + i] + t[i]);
+    for (int k = 0; k < 3; k++)
+      out_met(4 + 6 + m.q_perm[3 * l + k], st.get(ST_JI + 3 * k) * y[0] + st.get(ST_JI + 3 * k + 1) * y[1] + st.get(ST_JI + 3 * k + 2) * y[2]);
   }
   double res = 0.0;
   if (ct) res = fmax(fabs(zl[0]) - mu * zl[2], fabs(zl[1]) - mu * zl[2]);

@@ -1217,6 +1217,25 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
     tauc[i] = s;
   }
   for (int k = 0; k < 12; k++) out_tau(k, (status == ST_SINGULAR) ? T(0.0) : tauc[m.act_perm[k]]);
+  {
+    // generalized accelerations of the QP solution, rows 4..21 of out_met (optional consumer: the
+    // forward step of the closed-loop rollout): vd_b = a_b, vd_l = Ji (a_foot_l - Jfb_l a_b)
+    T ab[6];
+    for (int i = 0; i < 6; i++) {
+      T sab = ab0[i];
+      for (int c = 0; c < NZ; c++) sab = sab + B[i][c] * z[c];
+      ab[i] = sab;
+      out_met(4 + i, sab);
+    }
+    for (int l = 0; l < 4; l++) {
+      bool ctl = (mask >> l) & 1;
+      T rr[3] = {K[l].rf(0), K[l].rf(1), K[l].rf(2)}, t[3], y[3], vd[3];
+      cross(ab, rr, t);
+      for (int i = 0; i < 3; i++) y[i] = (ctl ? bc[l][i] : z[3 * l + i]) - (ab[3 + i] + t[i]);
+      rotv(D[l].Ji, y, vd);
+      for (int k = 0; k < 3; k++) out_met(4 + 6 + m.q_perm[3 * l + k], vd[k]);
+    }
+  }
   // primal residual: worst friction / torque-box violation
   T res = T(0.0);
   for (int l = 0; l < 4; l++)

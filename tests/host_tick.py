@@ -31,7 +31,7 @@ def _p(a):
 
 
 def run(kind, flat, q, v, targets, mask, mu=None, mass_scale=None, params12=None, q_perm=None, act_perm=None,
-        quad=False):
+        quad=False, want_vdot=False):
     q, v, targets = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, v, targets))
     mask = np.ascontiguousarray(mask, dtype=np.uint8)
     flat = np.ascontiguousarray(flat, dtype=np.float64)
@@ -43,12 +43,18 @@ def run(kind, flat, q, v, targets, mask, mu=None, mass_scale=None, params12=None
     qp = None if q_perm is None else np.ascontiguousarray(q_perm, dtype=np.int32)
     ap = None if act_perm is None else np.ascontiguousarray(act_perm, dtype=np.int32)
     k = {"id": 0, "mptc": 1, "pc": 2, "clf": 3}[kind.lower()] if isinstance(kind, str) else int(kind)
+    vdot = np.zeros((18, n)) if want_vdot else None
+    lib().host_set_vdot_sink.argtypes = [C.c_void_p]
+    lib().host_set_vdot_sink(vdot.ctypes.data_as(C.c_void_p) if want_vdot else None)
     fn = lib().host_quad_batch if quad else lib().host_tick_batch
     rc = fn(k, _p(flat), _p(pp), qp.ctypes.data_as(_ip) if qp is not None else None,
                                ap.ctypes.data_as(_ip) if ap is not None else None, n, n, _p(q), _p(v),
                                _p(targets), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), _p(mu), _p(ms),
                                _p(tau), _p(met), st.ctypes.data_as(_ip), it.ctypes.data_as(_ip))
     assert rc == 0
+    lib().host_set_vdot_sink(None)
+    if want_vdot:
+        return tau, met, st, it, vdot
     return tau, met, st, it
 
 

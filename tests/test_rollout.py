@@ -1,0 +1,96 @@
+"""generalized-acceleration output, forward step and the device-resident closed loop."""
+import numpy as np
+import pytest
+
+import host_tick as ht
+from oracle import oracle_py as orc
+from oracle import traj_oracle as to
+from quadruped_drake_amd import workloads
+
+
+@pytest.mark.parametrize("cfg,kind", [(3, "mptc"), (2, "id"), (3, "pc"), (3, "clf")])
+def test_vdot_of_kernel_math_equals_oracle_qp_vd(cfg, kind):
+    """vd is solver-independent (unique): the kernels' reduced solution must reproduce x[:18] of the literal QP."""
+    b = workloads.make_batch(cfg, n=24)
+    t = orc.load_model_json(b["model"]); m = orc.model(b["model"]); p = orc.params(kind)
+    for quad in ((False, True) if kind != "clf" else (False,)):
+        _, _, st, _, vd = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], quad=quad, want_vdot=True)
+        for i in range(24):
+            ct = [(int(b["mask"][i]) >> k) & 1 for k in range(4)]
+            _, _, _, qp = orc.control_law(kind, m, p, b["q"][:, i], b["v"][:, i], b["targets"][:, i], ct, want_qp=True)
+            assert np.abs(vd[:, i] - qp["x"][:18]).max() < 1e-9 * (1 + np.abs(qp["x"][:18]).max())
+
+
+def test_integrator_oracle_properties():
+    rng = np.random.default_rng(0)
+    b = workloads.make_batch(3, n=16)
+    vd = rng.normal(0, 5, (18, 16))
+    q1, v1 = to.integrate(b["q"], b["v"], vd, 5e-3)
+    assert np.allclose(np.linalg.norm(q1[:4], axis=0), 1.0, atol=1e-15)
+    assert np.allclose(v1, b["v"] + 5e-3 * vd)
+    assert np.allclose(q1[4:7], b["q"][4:7] + 5e-3 * v1[3:6]) and np.allclose(q1[7:], b["q"][7:] + 5e-3 * v1[6:])
+    # pure rotation about world z by w dt
+    q0 = np.zeros((19, 1)); q0[0] = 1; v0 = np.zeros((18, 1)); v0[2] = 2.0
+    q2, _ = to.integrate(q0, v0, np.zeros((18, 1)), 0.1)
+    assert np.allclose(q2[:4, 0], [np.cos(0.1), 0, 0, np.sin(0.1)])
+
+
+@pytest.mark.gpu
+def test_gpu_vdot_and_integrate_match_oracles():
+    import torch
+    from quadruped_drake_amd import MPTCController
+    b = workloads.make_batch(3, n=512)
+    ctrl = MPTCController(max_batch=512, device=0)
+    up = lambda x: torch.tensor(x, device="cuda:0")
+    q, v, tg, mk = up(b["q"]), up(b["v"]), up(b["targets"]), up(b["mask"])
+    vd = torch.zeros((18, 512), dtype=torch.float64, device="cuda:0")
+    ctrl.set_vdot_output(vd)
+    tau, met, st = ctrl.step(q, v, tg, mk)
+    ctrl.sync()
+    t = orc.load_model_json("mini_cheetah")
+    _, _, st_h, _, vd_h = ht.run("mptc", t["flat"], b["q"], b["v"], b["targets"], b["mask"], want_vdot=True)
+    assert np.abs(vd.cpu().numpy() - vd_h).max() < 1e-8 * (1 + np.abs(vd_h).max())
+    ctrl.integrate(q, v, vd, 5e-3)
+    ctrl.sync()
+    q_o, v_o = to.integrate(b["q"], b["v"], vd.cpu().numpy(), 5e-3)
+    assert np.allclose(q.cpu().numpy(), q_o, rtol=0, atol=1e-14) and np.allclose(v.cpu().numpy(), v_o, rtol=0, atol=1e-14)
+    ctrl.set_vdot_output(None)
+    ctrl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["id", "mptc"])
+def test_closed_loop_standing_rollout(kind):
+    """simulate.py:171-179 initial state, planners/simple.py standing targets, 200 ticks of dt = 5e-3
+    (simulate.py:21): the robot keeps standing, feet stay put, every tick is solved."""
+    import torch
+    from quadruped_drake_amd import IDController, MPTCController
+    from quadruped_drake_amd.trajectory import TrunkTrajectory
+    import energy_model as em
+    n = 64
+    q0, v0 = workloads.nominal_state("mini_cheetah", n)
+    rng = np.random.default_rng(3)
+    q0[7:] += rng.uniform(-0.05, 0.05, (12, n))           # slightly perturbed joints
+    st_t = workloads.standing_targets("mini_cheetah", 1)[:, 0]
+    model = em.load("mini_cheetah")
+    feet0 = np.array([[f["p"] for f in em.bodies(model, q0[:, i])[1]] for i in range(n)])
+    # stance feet are pinned by the QP's contact rows; put the (unused) foot targets anywhere
+    traj = TrunkTrajectory(np.zeros(0), np.zeros((0, 54)), np.zeros(0, np.uint8), wait_time=1e9, device=0,
+                           standing_targets=st_t, standing_mask=0b1111)
+    ctrl = (IDController if kind == "id" else MPTCController)(max_batch=n, device=0)
+    q = torch.tensor(q0, device="cuda:0"); v = torch.tensor(v0, device="cuda:0")
+    time = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    ctrl.stats(reset=True)
+    tau, met, st, tg, mk = ctrl.rollout(traj, 200, 5e-3, q, v, time)
+    ctrl.sync()
+    s = ctrl.stats()
+    assert s["ticks"] == 200 * n and s["status_nonzero"] == 0
+    qf = q.cpu().numpy(); vf = v.cpu().numpy()
+    assert np.allclose(time.cpu().numpy(), 1.0, atol=1e-9)
+    assert np.isfinite(qf).all() and np.allclose(np.linalg.norm(qf[:4], axis=0), 1.0, atol=1e-12)
+    assert np.abs(qf[6] - 0.3).max() < 0.02 and np.abs(qf[4:6]).max() < 0.02         # body converges to the 0.3 m target
+    assert np.abs(vf).max() < 0.2                                                   # and comes to rest
+    feet1 = np.array([[f["p"] for f in em.bodies(model, qf[:, i])[1]] for i in range(n)])
+    assert np.abs(feet1 - feet0).max() < 2e-3                                       # stance feet did not slide
+    assert (mk.cpu().numpy() == 0b1111).all() and np.array_equal(tg.cpu().numpy()[:, 0], st_t)
+    ctrl.close()

@@ -32,6 +32,8 @@ template <class T> static double val(const T& x);
 template <> double val<double>(const double& x) { return x; }
 template <> double val<Cnt>(const Cnt& x) { return x.v; }
 
+static double* g_vdot = nullptr;  // optional [18][stride] sink for the generalized accelerations (rows 4..21 of out_met)
+
 template <class T>
 static int run_one(int kind, const wbc::ModelC& m, const wbc::ParamsC& P, int i, int stride, const double* q,
                    const double* v, const double* tg, unsigned mask, double mu, double ms, double* tau,
@@ -42,7 +44,10 @@ static int run_one(int kind, const wbc::ModelC& m, const wbc::ParamsC& P, int i,
     return T(tg[(size_t)(r - 37) * stride + i]);
   };
   auto ot = [&](int k, T x) { tau[(size_t)k * stride + i] = val<T>(x); };
-  auto om = [&](int k, T x) { if (met) met[(size_t)k * stride + i] = val<T>(x); };
+  auto om = [&](int k, T x) {
+    if (k >= 4) { if (g_vdot) g_vdot[(size_t)(k - 4) * stride + i] = val<T>(x); return; }
+    if (met) met[(size_t)k * stride + i] = val<T>(x);
+  };
   if (kind == wbc::KIND_ID) return wbc::tick<T, wbc::KIND_ID>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
   if (kind == wbc::KIND_PC) return wbc::tick<T, wbc::KIND_PC>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
   if (kind == wbc::KIND_CLF) return wbc::tick<T, wbc::KIND_CLF>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
@@ -73,6 +78,8 @@ int host_tick_batch(int kind, const double* flat215, const double* params12, con
   return 0;
 }
 
+void host_set_vdot_sink(double* vdot) { g_vdot = vdot; }
+
 // Mean operation counts per tick over the batch: out[6] = add, mul, div, sqrt, trig, cmp.
 int host_tick_count(int kind, const double* flat215, const double* params12, int n, int stride,
                     const double* q, const double* v, const double* tg, const unsigned char* mask,
@@ -94,7 +101,7 @@ int host_tick_count(int kind, const double* flat215, const double* params12, int
       return Cnt(tg[(size_t)(r - 37) * stride + i]);
     };
     auto ot = [&](int k, Cnt x) { t1[k] = x.v; };
-    auto om = [&](int k, Cnt x) { m1[k] = x.v; };
+    auto om = [&](int k, Cnt x) { if (k < 4) m1[k] = x.v; };
     Cnt muv(mu ? mu[i] : P.mu), msv(mass_scale ? mass_scale[i] : 1.0);
     if (kind == wbc::KIND_ID) wbc::tick<Cnt, wbc::KIND_ID>(m, P, in, mask[i], muv, msv, ot, om, &it);
     else if (kind == wbc::KIND_PC) wbc::tick<Cnt, wbc::KIND_PC>(m, P, in, mask[i], muv, msv, ot, om, &it);
@@ -184,7 +191,10 @@ extern "C" int host_quad_batch(int kind, const double* flat215, const double* pa
         return tg[(size_t)(r - 37) * stride + i];
       };
       auto ot = [&](int k, double x) { tau[(size_t)k * stride + i] = x; };
-      auto om = [&](int k, double x) { if (l == 0 && met) met[(size_t)k * stride + i] = x; };
+      auto om = [&](int k, double x) {
+        if (k >= 4) { if (g_vdot && (k >= 10 || l == 0)) g_vdot[(size_t)(k - 4) * stride + i] = x; return; }
+        if (l == 0 && met) met[(size_t)k * stride + i] = x;
+      };
       int it = 0, st;
       double mui = mu ? mu[i] : P.mu, msi = mass_scale ? mass_scale[i] : 1.0;
       wbc::LegKin<double> K;
