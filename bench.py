@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--per-gpu", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--config", type=int, default=0, help="override workload config (2,3,4,5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", default="auto", choices=["auto", "lane", "quad"], help="kernel variant (A/B runs)")
+    ap.add_argument("--variant", default="auto", choices=["auto", "lane", "quad", "hex"], help="kernel variant (A/B runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work (core-seconds) for the baseline sample")
     return ap.parse_args()
 
@@ -134,7 +134,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
                 tr = json.load(f)
-            ent = tr.get("%s_cfg%d_n%d_%s" % (shard["kind"], cfg, n, "lane" if a.variant == "lane" else "quad"))
+            ent = tr.get("%s_cfg%d_n%d_%s" % (shard["kind"], cfg, n, a.variant if a.variant in ("lane", "hex") else "quad"))
             if ent:
                 traffic = ent["bytes_per_launch"]
         except (OSError, ValueError):
@@ -152,7 +152,7 @@ def main():
                 "domain_randomised": mu is not None, "parallelism": "batch-shard x%d" % world},
             "roofline": {"bound": "valu-f64", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "%s<%s>" % ("wbc_tick_kernel" if a.variant == "lane" else "wbc_quad_kernel", shard["kind"].upper()),
+                         "kernel": "%s<%s>" % ({"lane": "wbc_tick_kernel", "hex": "wbc_hex_kernel"}.get(a.variant, "wbc_quad_kernel"), shard["kind"].upper()),
                          "kernel_ms": ms_per_launch, "flops_per_tick": flops,
                          "hbm": {"achieved_GBs": bpt * n / sec / 1e9, "peak_GBs": PEAK_HBM_GBS,
                                  "frac": bpt * n / sec / 1e9 / PEAK_HBM_GBS, "bytes_per_tick": bpt},

@@ -198,7 +198,7 @@ class BatchedController:
 
     def set_variant(self, variant):
         """0 = auto, 1 = lane-per-robot kernel, 2 = quad-per-robot kernel."""
-        v = {"auto": 0, "lane": 1, "quad": 2}.get(variant, variant)
+        v = {"auto": 0, "lane": 1, "quad": 2, "hex": 3}.get(variant, variant)
         _lib.check(self._L.wbc_set_variant(self._h, int(v)))
 
     def kernel_info(self):

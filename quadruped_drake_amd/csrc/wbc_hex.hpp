@@ -1,0 +1,715 @@
+// wbc_hex.hpp -- one control tick computed by SIXTEEN lanes (one DPP row) per robot (product math, v4).
+//
+// Why (profiles/r01/cuts.md, profiles/r02): the quad mapping (wbc_quad.hpp) gives only N/16 wavefronts
+// (256 at N = 4096: one SIMD of four busy per CU) and its per-lane state (three z-space columns, three
+// rows of J) does not fit 512 registers -- 1.4 KB/lane of scratch that overflows L2 once two waves
+// share a CU.  Here lane h = 4*leg + sub of a 16-lane DPP row:
+//   * leg dynamics are replicated on the four sub-lanes of a leg, except the three Newton-Euler passes
+//     of the MPTC law (bias, +xi, -xi), which run concurrently on sub-lanes 0/1/2 (same code, other data);
+//   * every z-space object is distributed one COLUMN per lane: lane (leg, j<3) owns reduced variable
+//     3*leg+j (its column of B = G_b^-1 [W|-X], of the QR factor, its row of J = R^-1); lane (leg, 3)
+//     owns the right-hand side / ab0 column, so "matrix | rhs" needs no separate code path;
+//   * rows of the least-squares blocks are owned the same way (lane (leg,i) = row 3*leg+i), so every
+//     block is an all-pairs product row-vector(6) . column(6) fed by single-instruction
+//     v_mov_b64_dpp row_newbcast broadcasts from compile-time lanes;
+//   * sums over the four legs are two DPP stages (row_ror:8, row_ror:4), bit-identical on all lanes.
+// A wavefront holds 4 robots: N/4 wavefronts, ~1/2 the instructions per wavefront of the quad kernel
+// and no scratch.
+//
+// `Q` is the communication policy: HexDev (wbc_kernels.hip) on the GPU, a 16-fibre lock-step
+// emulation in tools/host_tick.cpp for CPU-side validation.
+#pragma once
+#include "wbc_quad.hpp"
+
+namespace wbc {
+
+// lane (within the 16-lane row) that owns z-space column / row k = 3*leg + coordinate
+WBC_HD constexpr int hex_lane(int k) { return 4 * (k / 3) + (k % 3); }
+
+// Distributed Householder append: fold P dense rows into the upper-triangular factor.
+// Lane hex_lane(c) holds column c: Rcol[12], Acol[P]; the lanes with sub == 3 hold the right-hand side
+// as one more column.  Already-pivoted columns are left with O(ulp) residue below the diagonal of R
+// (never read) instead of being zeroed: no per-step predication.
+template <class Q, int P>
+WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
+#pragma unroll
+  for (int k = 0; k < NZ; k++) {
+    const int piv = hex_lane(k);
+    double col[P];
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+      col[i] = qo.bcast16(Acol[i], piv);
+      t += col[i] * Acol[i];
+    }
+    const double s2 = qo.bcast16(t, piv);
+    const double rkk = qo.bcast16(Rcol[k], piv);
+    if (!(s2 > 0.0)) continue;
+    const double nrm = sqrt(rkk * rkk + s2);
+    const double alpha = (rkk > 0.0) ? -nrm : nrm;
+    const double v0 = rkk - alpha;
+    const double beta = 1.0 / (nrm * (nrm + fabs(rkk)));  // = 2 / (s2 + v0^2)
+    const double s = (v0 * Rcol[k] + t) * beta;
+    Rcol[k] -= s * v0;
+#pragma unroll
+    for (int i = 0; i < P; i++) Acol[i] -= s * col[i];
+  }
+}
+
+// Goldfarb-Idnani on the friction rows, 16 lanes per robot.  Jr = own row of J (J J' = H^-1; zero on
+// the sub == 3 lanes), z = own entry.  Friction row p = 4*leg + r is evaluated on lane p itself.
+// Same flat wave-uniform loop as quad_gi (one algorithm step per trip for every unfinished robot).
+template <class Q>
+WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, double inv_s, QuadShared& sh,
+                  int* iters_out, double vrow_own = 0.0, double vc = 0.0, double pc_inv = 0.0) {
+  const int l = h >> 2, sb = h & 3;
+  const bool pc = pc_inv > 0.0;
+  int q = 0, iters = 0, status = ST_OK;
+  unsigned active = 0u;
+  const int maxit = 200;
+  bool done = false, need_pick = true;
+  int p = -1;
+  double sp = 0.0, npl = 0.0;
+  for (int trip = 0; trip < maxit; trip++) {
+    if (!done && need_pick) {
+      const double zinf = qo.max16(fabs(z));
+      const double tol = 1e-13 * (1.0 + zinf);
+      sp = -tol;
+      p = -1;
+      const double z0 = qo.leg_bcast(z, 0), z1 = qo.leg_bcast(z, 1), z2 = qo.leg_bcast(z, 2);
+      if (ct) {
+        const bool act = (active >> h) & 1u;
+        const double zc = (sb >> 1) ? z1 : z0;
+        const double sv = ((sb & 1) ? inv_s : -inv_s) * zc + mu_n * z2;
+        if (!act && sv < sp) { sp = sv; p = h; }
+      }
+      qo.argmin16(sp, p);
+      if (pc && !((active >> 16) & 1u)) {
+        const double sv = -(qo.sum16(vrow_own * z) + vc) * pc_inv;
+        if (sv < sp) { sp = sv; p = 16; }
+      }
+      if (p < 0) {
+        done = true;
+      } else {
+        if (p == 16) {
+          npl = -vrow_own * pc_inv;
+        } else {
+          const int owner = p >> 2, rr = p & 3;
+          const double sg = (rr & 1) ? inv_s : -inv_s;
+          const double mine = (sb == 0) ? ((rr >> 1) ? 0.0 : sg) : ((sb == 1) ? ((rr >> 1) ? sg : 0.0) : ((sb == 2) ? mu_n : 0.0));
+          npl = (l == owner) ? mine : 0.0;
+        }
+        sh.u[q] = 0.0;
+        need_pick = false;
+      }
+    }
+    if (qo.wave_all(done)) break;
+    if (done) continue;
+    iters++;
+    double d[NZ], dn = 0.0, d2n = 0.0;
+#pragma unroll
+    for (int k = 0; k < NZ; k++) {
+      d[k] = qo.sum16(Jr[k] * npl);
+      dn += d[k] * d[k];
+      if (k >= q) d2n += d[k] * d[k];
+    }
+    double zd = 0.0;
+#pragma unroll
+    for (int k = 0; k < NZ; k++) zd += Jr[k] * ((k >= q) ? d[k] : 0.0);
+    double r[NZ];
+    int ldrop;
+    double t1n, t1d;
+    const int qmax = qo.wave_max_int(q);
+    if (qmax <= 3) gi_dual<3>(sh, q, d, r, ldrop, t1n, t1d);
+    else if (qmax <= 6) gi_dual<6>(sh, q, d, r, ldrop, t1n, t1d);
+    else gi_dual<NZ>(sh, q, d, r, ldrop, t1n, t1d);
+    const bool have_t1 = ldrop >= 0;
+    const double t1 = have_t1 ? t1n / t1d : 0.0;
+    const bool dependent = !(d2n > 1e-22 * dn) || q == NZ;
+    const double znp = qo.sum16(zd * npl);
+    const double t2 = dependent ? 0.0 : -sp / znp;
+    if (dependent && !have_t1) { status = ST_SINGULAR; done = true; continue; }
+    const bool full = !dependent && (!have_t1 || !(t1 < t2));
+    const double t = full ? t2 : t1;
+#pragma unroll
+    for (int k = 0; k < NZ; k++)
+      if (k < q) sh.u[k] -= t * r[k];
+    sh.u[q] += t;
+    if (!dependent) z += t * zd;
+    if (full) {
+      double dq = 0.0;
+#pragma unroll
+      for (int k = 0; k < NZ; k++) dq = (k == q) ? d[k] : dq;
+      const double nrm = sqrt(d2n);
+      const double alpha = (dq > 0.0) ? -nrm : nrm;
+      const double vq = dq - alpha;
+      const double vv = d2n - dq * dq + vq * vq;
+      if (vv > 0.0) {
+        const double beta = 2.0 / vv;
+        double w = 0.0;
+        double hv[NZ];
+#pragma unroll
+        for (int k = 0; k < NZ; k++) {
+          hv[k] = (k < q) ? 0.0 : ((k == q) ? vq : d[k]);
+          w += Jr[k] * hv[k];
+        }
+        w *= beta;
+#pragma unroll
+        for (int k = 0; k < NZ; k++) Jr[k] -= w * hv[k];
+      }
+#pragma unroll
+      for (int k = 0; k < NZ; k++)
+        if (k < q) sh.Rq[k][q] = d[k];
+      sh.Rq[q][q] = 1.0 / alpha;
+      sh.A[q] = p;
+      active |= (1u << p);
+      q++;
+      need_pick = true;
+      continue;
+    }
+    // partial / pure dual step: drop active constraint ldrop (see quad_gi for the storage convention)
+    active &= ~(1u << sh.A[ldrop]);
+    for (int j = ldrop; j < q - 1; j++) {
+      sh.A[j] = sh.A[j + 1];
+      sh.u[j] = sh.u[j + 1];
+      for (int k = 0; k <= j + 1; k++) sh.Rq[k][j] = sh.Rq[k][j + 1];
+    }
+    sh.u[q - 1] = sh.u[q];
+    q--;
+    sh.u[q + 1] = 0.0;
+    for (int j = ldrop; j < q; j++) {
+      const double a = sh.Rq[j][j], bb = 1.0 / sh.Rq[j + 1][j];
+      const double hh = sqrt(a * a + bb * bb), c = a / hh, sn = bb / hh;
+      sh.Rq[j][j] = 1.0 / hh;
+      for (int k = j + 1; k < q; k++) {
+        const double x = sh.Rq[j][k], y = sh.Rq[j + 1][k];
+        sh.Rq[j][k] = c * x + sn * y;
+        sh.Rq[j + 1][k] = c * y - sn * x;
+      }
+#pragma unroll
+      for (int jj = 0; jj < NZ - 1; jj++) {
+        if (jj != j) continue;
+        const double x = Jr[jj], y = Jr[jj + 1];
+        Jr[jj] = c * x + sn * y;
+        Jr[jj + 1] = c * y - sn * x;
+      }
+    }
+    if (!dependent) sp = qo.sum16(npl * z) - ((p == 16) ? vc * pc_inv : 0.0);
+  }
+  *iters_out = iters;
+  if (!done && status == ST_OK) status = ST_ITER;
+  return status;
+}
+
+// per-lane pick of element `sb` (0..2) of a replicated triple
+WBC_HD double pick3(int sb, double a, double b, double c) { return (sb == 0) ? a : ((sb == 1) ? b : c); }
+
+// The tick.  Every lane of the row calls this with its own Q (lane id h = 4*leg + sub).
+// out_tau(row, x): lane (leg, j<3) writes the torque of joint 3*leg+j;  out_met: see the kernel.
+template <class Q, int KIND, class In, class OutTau, class OutMet>
+WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned mask, double mu, double mass_scale,
+                    QuadShared& sh, OutTau out_tau, OutMet out_met, int* iters_out) {
+  const int h = qo.lane();
+  const int l = h >> 2, sb = h & 3;
+  const bool ct = (mask >> l) & 1u;
+  const bool colv = sb < 3;  // owns a z-space column (else: the right-hand-side / ab0 column)
+  int status = ST_OK;
+  // ---------------- state (replicated on the 16 lanes)
+  double R0[9];
+  {
+    const double qw = in(0), qx = in(1), qy = in(2), qz = in(3);
+    const double s = 2.0 / (qw * qw + qx * qx + qy * qy + qz * qz);
+    R0[0] = 1.0 - s * (qy * qy + qz * qz); R0[1] = s * (qx * qy - qw * qz); R0[2] = s * (qx * qz + qw * qy);
+    R0[3] = s * (qx * qy + qw * qz); R0[4] = 1.0 - s * (qx * qx + qz * qz); R0[5] = s * (qy * qz - qw * qx);
+    R0[6] = s * (qx * qz - qw * qy); R0[7] = s * (qy * qz + qw * qx); R0[8] = 1.0 - s * (qx * qx + qy * qy);
+  }
+  const double p0[3] = {in(4), in(5), in(6)};
+  const double w0[3] = {in(19), in(20), in(21)};
+  const double v0[3] = {in(22), in(23), in(24)};
+  const double gz = m.gravity;
+  const double bm = m.base_mass * mass_scale;
+  double bmc[3], bI[6];
+  {
+    const double t[3] = {m.base_mc[0] * mass_scale, m.base_mc[1] * mass_scale, m.base_mc[2] * mass_scale};
+    rotv(R0, t, bmc);
+    rot_inertia(R0, m.base_I, bI);
+    for (int i = 0; i < 6; i++) bI[i] *= mass_scale;
+  }
+  double rpy[3], E[9], rpyd[3];
+  {
+    rpy[0] = atan2(R0[7], R0[8]);
+    rpy[1] = atan2(-R0[6], sqrt(R0[0] * R0[0] + R0[3] * R0[3]));
+    rpy[2] = atan2(R0[3], R0[0]);
+    const double cp = sqrt(R0[0] * R0[0] + R0[3] * R0[3]), sp = -R0[6];
+    const double icp = 1.0 / cp;
+    const double cy = R0[0] * icp, sy = R0[3] * icp;
+    E[0] = cp * cy; E[1] = -sy; E[2] = 0.0; E[3] = cp * sy; E[4] = cy; E[5] = 0.0; E[6] = -sp; E[7] = 0.0; E[8] = 1.0;
+    const double Ei[9] = {cy * icp, sy * icp, 0.0, -sy, cy, 0.0, cy * sp * icp, sy * sp * icp, 1.0};
+    rotv(Ei, w0, rpyd);
+  }
+  double xt_b[6], xdt_b[6], xdd_b[6], ades[6];
+  {
+    double tg_pb[3], tg_pdb[3], tg_pddb[3], tg_rpy[3], tg_rpyd[3], tg_rpydd[3];
+    for (int i = 0; i < 3; i++) {
+      tg_pb[i] = in(37 + i); tg_pdb[i] = in(40 + i); tg_pddb[i] = in(43 + i);
+      tg_rpy[i] = in(46 + i); tg_rpyd[i] = in(49 + i); tg_rpydd[i] = in(52 + i);
+    }
+    for (int i = 0; i < 3; i++) { xt_b[i] = rpy[i] - tg_rpy[i]; xt_b[3 + i] = p0[i] - tg_pb[i]; }
+    if (KIND == KIND_ID) {
+      double rpydd_des[3], od[3];
+      for (int i = 0; i < 3; i++) {
+        ades[3 + i] = tg_pddb[i] - P.Kp_body_p * xt_b[3 + i] - P.Kd_body_p * (v0[i] - tg_pdb[i]);
+        rpydd_des[i] = tg_rpydd[i] - P.Kp_body_rpy * xt_b[i] - P.Kd_body_rpy * (rpyd[i] - tg_rpyd[i]);
+      }
+      rotv(E, rpydd_des, od);
+      for (int i = 0; i < 3; i++) { ades[i] = od[i]; xdt_b[i] = 0.0; xdt_b[3 + i] = 0.0; xdd_b[i] = 0.0; xdd_b[3 + i] = 0.0; }
+    } else {
+      double om_rt[3], xdn[3], xddn[3];
+      rotv(E, rpyd, om_rt);      // literal E(rpy) * rpyd round trip of mptc_controller.py:245
+      rotv(E, tg_rpyd, xdn);
+      rotv(E, tg_rpydd, xddn);
+      for (int i = 0; i < 3; i++) {
+        xdt_b[i] = om_rt[i] - xdn[i];
+        xdt_b[3 + i] = v0[i] - tg_pdb[i];
+        xdd_b[i] = xddn[i];
+        xdd_b[3 + i] = tg_pddb[i];
+        ades[i] = 0.0; ades[3 + i] = 0.0;
+      }
+    }
+  }
+  // ---------------- own leg (replicated on its four sub-lanes unless noted)
+  double rf[3], Jdv[3], pd[3], rd[3], hl[3];
+  double X[18], Y[18], Pm[9], Jl[9], Ji[9], Mll6[6];
+  double hbN[6];
+  double lm = 0.0, lh[3] = {0.0, 0.0, 0.0}, lI[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  double Cb_leg[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, Cl[3] = {0.0, 0.0, 0.0}, xi[3] = {0.0, 0.0, 0.0};
+  double xt_s[3], xdt_s[3], xdd_s[3];
+  double jdxi[3] = {0.0, 0.0, 0.0};  // Jd xi (MPTC swing rows)
+  {
+    LegKin<double> K;
+    LegDyn<double> D;
+    double qd[3];
+    const double mass3[3] = {m.link[l][0].mass, m.link[l][1].mass, m.link[l][2].mass};
+    {
+      double sn[3], cs[3];
+      for (int k = 0; k < 3; k++) {
+        const int row = m.q_perm[3 * l + k];
+        const double th = in(7 + row);
+        wbc_sincos(th, sn[k], cs[k]);
+        qd[k] = in(25 + row);
+      }
+      leg_fk(m, l, R0, sn, cs, K);
+    }
+    leg_crba(mass3, K, D, lm, lh, lI);
+    for (int i = 0; i < 3; i++) rf[i] = K.rf(i);
+    for (int k = 0; k < 3; k++) {
+      const double d[3] = {rf[0] - K.r(k, 0), rf[1] - K.r(k, 1), rf[2] - K.r(k, 2)};
+      const double axv[3] = {K.ax(k, 0), K.ax(k, 1), K.ax(k, 2)};
+      double c[3];
+      cross(axv, d, c);
+      for (int i = 0; i < 3; i++) Jl[3 * i + k] = c[i];
+    }
+    const double det = inv3(Jl, Ji);
+    if (qo.any16(!(fabs(det) > 1e-12))) status = ST_SINGULAR;
+    double Mf[9];
+    sym_to_full(D.Mll, Mf);
+    mm3(Mf, Ji, Pm);  // Pm = Mll Ji
+    for (int i = 0; i < 6; i++) Mll6[i] = D.Mll[i];
+    // foot velocity relative to the base origin: w0 x rf + Jl qd
+    {
+      double t[3];
+      cross(w0, rf, t);
+      for (int i = 0; i < 3; i++) {
+        rd[i] = t[i] + Jl[3 * i] * qd[0] + Jl[3 * i + 1] * qd[1] + Jl[3 * i + 2] * qd[2];
+        pd[i] = v0[i] + rd[i];
+      }
+    }
+    for (int i = 0; i < 3; i++) {
+      const double pf = p0[i] + rf[i];
+      const double tp = in(37 + 18 + 9 * l + i), tpd = in(37 + 21 + 9 * l + i), tpdd = in(37 + 24 + 9 * l + i);
+      xt_s[i] = ct ? 0.0 : pf - tp;
+      xdt_s[i] = ct ? 0.0 : pd[i] - tpd;
+      xdd_s[i] = ct ? 0.0 : tpdd;
+    }
+    if (KIND != KIND_ID) {
+      double Mli[9];
+      inv3(Mf, Mli);
+      double t[3], jfb[3];
+      cross(xdt_b, rf, t);
+      for (int i = 0; i < 3; i++) jfb[i] = xdt_b[3 + i] + t[i];
+      if (ct) {
+        double yx[3];
+        for (int i = 0; i < 3; i++) {
+          double s = 0.0;
+          for (int j = 0; j < 6; j++) s += D.Mbl[3 * j + i] * xdt_b[j];
+          yx[i] = s - (Pm[3 * i] * jfb[0] + Pm[3 * i + 1] * jfb[1] + Pm[3 * i + 2] * jfb[2]);
+        }
+        for (int i = 0; i < 3; i++)
+          xi[i] = -(Mli[3 * i] * yx[0] + Mli[3 * i + 1] * yx[1] + Mli[3 * i + 2] * yx[2]) -
+                  (Ji[3 * i] * jfb[0] + Ji[3 * i + 1] * jfb[1] + Ji[3 * i + 2] * jfb[2]);
+      } else {
+        const double y[3] = {xdt_s[0] - jfb[0], xdt_s[1] - jfb[1], xdt_s[2] - jfb[2]};
+        rotv(Ji, y, xi);
+      }
+    }
+    // Newton-Euler: sub-lanes 0 and 3 run the bias pass h(v) (with gravity); for the MPTC laws
+    // sub-lane 1 runs h(v + xi) and sub-lane 2 h(v - xi) (gravity-free):  C xi = 1/4 [h(v+xi) - h(v-xi)].
+    {
+      const double c1 = (KIND == KIND_ID) ? 0.0 : ((sb == 1) ? 1.0 : ((sb == 2) ? -1.0 : 0.0));
+      const double gq = (KIND == KIND_ID || sb == 0 || sb == 3) ? gz : 0.0;
+      const double wv[3] = {w0[0] + c1 * xdt_b[0], w0[1] + c1 * xdt_b[1], w0[2] + c1 * xdt_b[2]};
+      const double qv[3] = {qd[0] + c1 * xi[0], qd[1] + c1 * xi[1], qd[2] + c1 * xi[2]};
+      double hq[3], Nq[3], Fq[3];
+      leg_rnea<double, true>(mass3, K, wv, qv, gq, hq, Nq, Fq, &D);
+      if (KIND == KIND_ID) {
+        for (int i = 0; i < 3; i++) { hl[i] = hq[i]; hbN[i] = Nq[i]; hbN[3 + i] = Fq[i]; Jdv[i] = D.Jdv[i]; }
+      } else {
+        double jx[3];
+        for (int i = 0; i < 3; i++) jx[i] = D.Jd[3 * i] * xi[0] + D.Jd[3 * i + 1] * xi[1] + D.Jd[3 * i + 2] * xi[2];
+        for (int i = 0; i < 3; i++) {
+          hl[i] = qo.leg_bcast(hq[i], 0);
+          hbN[i] = qo.leg_bcast(Nq[i], 0);
+          hbN[3 + i] = qo.leg_bcast(Fq[i], 0);
+          Jdv[i] = qo.leg_bcast(D.Jdv[i], 0);
+          jdxi[i] = qo.leg_bcast(jx[i], 0);
+          Cl[i] = 0.25 * (qo.leg_bcast(hq[i], 1) - qo.leg_bcast(hq[i], 2));
+          Cb_leg[i] = 0.25 * (qo.leg_bcast(Nq[i], 1) - qo.leg_bcast(Nq[i], 2));
+          Cb_leg[3 + i] = 0.25 * (qo.leg_bcast(Fq[i], 1) - qo.leg_bcast(Fq[i], 2));
+        }
+      }
+    }
+    // X = Mbl Ji, Y = Mbl' - Pm Jfb
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 3; j++)
+        X[3 * i + j] = D.Mbl[3 * i] * Ji[j] + D.Mbl[3 * i + 1] * Ji[3 + j] + D.Mbl[3 * i + 2] * Ji[6 + j];
+    for (int i = 0; i < 3; i++) {
+      const double a0 = Pm[3 * i], a1 = Pm[3 * i + 1], a2 = Pm[3 * i + 2];
+      Y[6 * i + 0] = D.Mbl[0 * 3 + i] + (a1 * rf[2] - a2 * rf[1]);
+      Y[6 * i + 1] = D.Mbl[1 * 3 + i] + (a2 * rf[0] - a0 * rf[2]);
+      Y[6 * i + 2] = D.Mbl[2 * 3 + i] + (a0 * rf[1] - a1 * rf[0]);
+      Y[6 * i + 3] = D.Mbl[3 * 3 + i] - a0;
+      Y[6 * i + 4] = D.Mbl[4 * 3 + i] - a1;
+      Y[6 * i + 5] = D.Mbl[5 * 3 + i] - a2;
+    }
+  }
+  const double bc[3] = {ct ? (-P.Kd_contact * pd[0] - Jdv[0]) : 0.0, ct ? (-P.Kd_contact * pd[1] - Jdv[1]) : 0.0,
+                        ct ? (-P.Kd_contact * pd[2] - Jdv[2]) : 0.0};
+  // own row of t0 (without the Y ab0 part) and of the torque map's diagonal block D_l
+  // (-Jl' for a contact leg, Pm for a swing leg); meaningful on the column lanes (sub < 3)
+  double t0_own, Yrow[6], Drow[3];
+  {
+    double t0l[3];
+    for (int i = 0; i < 3; i++) t0l[i] = hl[i] + (Pm[3 * i] * bc[0] + Pm[3 * i + 1] * bc[1] + Pm[3 * i + 2] * bc[2]);
+    t0_own = pick3(sb, t0l[0], t0l[1], t0l[2]);
+    for (int k = 0; k < 6; k++) Yrow[k] = pick3(sb, Y[k], Y[6 + k], Y[12 + k]);
+    for (int j = 0; j < 3; j++)
+      Drow[j] = ct ? -pick3(sb, Jl[3 * j], Jl[3 * j + 1], Jl[3 * j + 2]) : pick3(sb, Pm[j], Pm[3 + j], Pm[6 + j]);
+  }
+  // ---------------- base: bias wrench, composite inertia -> Gs = G_b, kv
+  double Gs[6][6], kv[6];
+  {
+    double hb[6];
+    {
+      double t2[3], t3[3], Iw_w[3], t4[3];
+      const double g3[3] = {0.0, 0.0, gz};
+      cross(w0, bmc, t2);
+      cross(w0, t2, t2);
+      symv(bI, w0, Iw_w);
+      cross(w0, Iw_w, t3);
+      cross(bmc, g3, t4);
+      for (int i = 0; i < 3; i++) { hb[i] = t3[i] + t4[i]; hb[3 + i] = bm * g3[i] + t2[i]; }
+    }
+    for (int i = 0; i < 6; i++)
+      kv[i] = hb[i] + qo.legs_sum(hbN[i] + (ct ? (X[3 * i] * bc[0] + X[3 * i + 1] * bc[1] + X[3 * i + 2] * bc[2]) : 0.0));
+    const double Mc = bm + qo.legs_sum(lm);
+    double Hc[3], Ic[6];
+    for (int i = 0; i < 3; i++) Hc[i] = bmc[i] + qo.legs_sum(lh[i]);
+    for (int i = 0; i < 6; i++) Ic[i] = bI[i] + qo.legs_sum(lI[i]);
+    double Mbb[6][6];
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Mbb[i][j] = 0.0;
+    Mbb[0][0] = Ic[0]; Mbb[1][1] = Ic[1]; Mbb[2][2] = Ic[2];
+    Mbb[0][1] = Mbb[1][0] = Ic[3]; Mbb[0][2] = Mbb[2][0] = Ic[4]; Mbb[1][2] = Mbb[2][1] = Ic[5];
+    Mbb[0][4] = -Hc[2]; Mbb[0][5] = Hc[1];
+    Mbb[1][3] = Hc[2];  Mbb[1][5] = -Hc[0];
+    Mbb[2][3] = -Hc[1]; Mbb[2][4] = Hc[0];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Mbb[3 + j][i] = Mbb[i][3 + j];
+    Mbb[3][3] = Mc; Mbb[4][4] = Mc; Mbb[5][5] = Mc;
+    for (int i = 0; i < 6; i++) {
+      const double a0 = X[3 * i], a1 = X[3 * i + 1], a2 = X[3 * i + 2];
+      Gs[i][0] = Mbb[i][0] + qo.legs_sum(a1 * rf[2] - a2 * rf[1]);
+      Gs[i][1] = Mbb[i][1] + qo.legs_sum(a2 * rf[0] - a0 * rf[2]);
+      Gs[i][2] = Mbb[i][2] + qo.legs_sum(a0 * rf[1] - a1 * rf[0]);
+      Gs[i][3] = Mbb[i][3] - qo.legs_sum(a0);
+      Gs[i][4] = Mbb[i][4] - qo.legs_sum(a1);
+      Gs[i][5] = Mbb[i][5] - qo.legs_sum(a2);
+    }
+  }
+  // own column of [B | ab0]:  G_b bcol = (W_l or -X_l)[:, sub]  (sub < 3)  |  -kv  (sub == 3)
+  double bcol[6], ab0[6];
+  {
+    double Ab[6][7];
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) Ab[i][j] = Gs[i][j];
+    // W_l[:, j] = [rf x e_j ; e_j]
+    const double wc[6] = {pick3(sb, 0.0, -rf[2], rf[1]), pick3(sb, rf[2], 0.0, -rf[0]), pick3(sb, -rf[1], rf[0], 0.0),
+                          pick3(sb, 1.0, 0.0, 0.0), pick3(sb, 0.0, 1.0, 0.0), pick3(sb, 0.0, 0.0, 1.0)};
+    for (int i = 0; i < 6; i++) {
+      const double xc = pick3(sb, X[3 * i], X[3 * i + 1], X[3 * i + 2]);
+      Ab[i][6] = colv ? (ct ? wc[i] : -xc) : -kv[i];
+    }
+    const double rc = solve6<1>(Ab);
+    if (!(rc > 1e-12)) status = ST_SINGULAR;
+    for (int i = 0; i < 6; i++) {
+      bcol[i] = Ab[i][6];
+      ab0[i] = qo.leg_bcast(bcol[i], 3);
+    }
+  }
+  // ---------------- level-1 rows
+  const double eps = sqrt(P.eps2);
+  const double sw_b = sqrt(P.w_body), sw_f = sqrt(P.w_foot);
+  double Rcol[NZ];
+  double met_err = 0.0;
+  for (int i = 0; i < 6; i++) met_err += xt_b[i] * xt_b[i];
+  met_err += qo.legs_sum(xt_s[0] * xt_s[0] + xt_s[1] * xt_s[1] + xt_s[2] * xt_s[2]);
+  double met_V = 0.0, met_Vdot = 0.0;
+  double vrow_own = 0.0, vconst = 0.0;  // Vdot = met_Vdot + vconst + sum over column lanes of vrow_own * z
+  {
+    // diagonal rows: swing leg sqrt(w_foot) (ID) / 0 (MPTC); contact leg eps.  Row 3*leg+sub lives on lane (leg, sub).
+    double dval, drhs;
+    const double xdd_o = pick3(sb, xdd_s[0], xdd_s[1], xdd_s[2]), xt_o = pick3(sb, xt_s[0], xt_s[1], xt_s[2]),
+                 xdt_o = pick3(sb, xdt_s[0], xdt_s[1], xdt_s[2]), jdv_o = pick3(sb, Jdv[0], Jdv[1], Jdv[2]);
+    if (ct) { dval = eps; drhs = 0.0; }
+    else if (KIND == KIND_ID) {
+      const double des = xdd_o - P.Kp_foot * xt_o - P.Kd_foot * xdt_o;
+      dval = sw_f; drhs = sw_f * (des - jdv_o);
+    } else { dval = 0.0; drhs = 0.0; }
+#pragma unroll
+    for (int k = 0; k < NZ; k++) {
+      const double rk = qo.bcast16(drhs, hex_lane(k));
+      Rcol[k] = colv ? ((hex_lane(k) == h) ? dval : 0.0) : rk;
+    }
+  }
+  if (KIND == KIND_ID) {
+    double Acol[6];
+    for (int i = 0; i < 6; i++) Acol[i] = colv ? sw_b * bcol[i] : sw_b * (ades[i] - bcol[i]);
+    hex_qr_append<Q, 6>(qo, Rcol, Acol);
+  } else {
+    // ---- MPTC in task coordinates (derivation: wbc_tick.hpp / DESIGN.md)
+    double MiY[18], Mt_bl[18], Mt_ll[9];
+    {
+      double Mf[9], Mli[9];
+      sym_to_full(Mll6, Mf);
+      inv3(Mf, Mli);
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 6; j++) MiY[6 * i + j] = Mli[3 * i] * Y[j] + Mli[3 * i + 1] * Y[6 + j] + Mli[3 * i + 2] * Y[12 + j];
+    }
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 6; j++) Mt_bl[3 * j + i] = Ji[i] * Y[j] + Ji[3 + i] * Y[6 + j] + Ji[6 + i] * Y[12 + j];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) Mt_ll[3 * i + j] = Ji[i] * Pm[j] + Ji[3 + i] * Pm[3 + j] + Ji[6 + i] * Pm[6 + j];
+    double LJ_b[6], LJ_s[3];
+    {
+      double Cb_base[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      for (int sgi = 0; sgi < 2; sgi++) {
+        const double sg = sgi ? -0.25 : 0.25, s1 = sgi ? -1.0 : 1.0;
+        const double wv[3] = {w0[0] + s1 * xdt_b[0], w0[1] + s1 * xdt_b[1], w0[2] + s1 * xdt_b[2]};
+        double t2[3], t3[3], Iw_w[3];
+        cross(wv, bmc, t2);
+        cross(wv, t2, t2);
+        symv(bI, wv, Iw_w);
+        cross(wv, Iw_w, t3);
+        for (int i = 0; i < 3; i++) { Cb_base[i] += sg * t3[i]; Cb_base[3 + i] += sg * t2[i]; }
+      }
+      double gl[3], c[3];
+      for (int i = 0; i < 3; i++) gl[i] = Ji[i] * Cl[0] + Ji[3 + i] * Cl[1] + Ji[6 + i] * Cl[2];
+      cross(rf, gl, c);
+      for (int j = 0; j < 6; j++) {
+        double loc = Cb_leg[j] - ((j < 3) ? c[j] : gl[j - 3]);
+        if (ct) loc -= MiY[j] * Cl[0] + MiY[6 + j] * Cl[1] + MiY[12 + j] * Cl[2];
+        LJ_b[j] = Cb_base[j] + qo.legs_sum(loc);
+      }
+      for (int i = 0; i < 3; i++) LJ_s[i] = ct ? 0.0 : gl[i];
+    }
+    double s1_s[3];
+    {
+      double t[3];
+      cross(xdt_b, rd, t);
+      for (int i = 0; i < 3; i++) s1_s[i] = ct ? 0.0 : xdd_s[i] - Jdv[i] + t[i] + jdxi[i];
+    }
+    double Ls_s[3], Lx_s[3];
+    for (int i = 0; i < 3; i++) {
+      double a = Mt_ll[3 * i] * s1_s[0] + Mt_ll[3 * i + 1] * s1_s[1] + Mt_ll[3 * i + 2] * s1_s[2];
+      double b = Mt_ll[3 * i] * xdt_s[0] + Mt_ll[3 * i + 1] * xdt_s[1] + Mt_ll[3 * i + 2] * xdt_s[2];
+      for (int j = 0; j < 6; j++) { a += Mt_bl[3 * j + i] * xdd_b[j]; b += Mt_bl[3 * j + i] * xdt_b[j]; }
+      Ls_s[i] = ct ? 0.0 : a;
+      Lx_s[i] = ct ? 0.0 : b;
+    }
+    double c1_s[3];
+    {
+      double lv = 0.0, lvd = 0.0;
+      for (int i = 0; i < 3; i++) {
+        c1_s[i] = LJ_s[i] - Ls_s[i] + P.Kp_foot * xt_s[i] + P.Kd_foot * xdt_s[i];
+        lv += 0.5 * P.Kp_foot * xt_s[i] * xt_s[i] + 0.5 * xdt_s[i] * Lx_s[i];
+        lvd += -P.Kd_foot * xdt_s[i] * xdt_s[i] + xdt_s[i] * c1_s[i];
+      }
+      met_V += qo.legs_sum(lv);
+      met_Vdot += qo.legs_sum(lvd);
+    }
+    double Acol[18];
+    {
+      double A[18];  // Ji Jfb
+      for (int i = 0; i < 3; i++) {
+        const double a0 = Ji[3 * i], a1 = Ji[3 * i + 1], a2 = Ji[3 * i + 2];
+        A[6 * i + 0] = -(a1 * rf[2] - a2 * rf[1]);
+        A[6 * i + 1] = -(a2 * rf[0] - a0 * rf[2]);
+        A[6 * i + 2] = -(a0 * rf[1] - a1 * rf[0]);
+        A[6 * i + 3] = a0; A[6 * i + 4] = a1; A[6 * i + 5] = a2;
+      }
+      // column lanes: vrow_own = [swing] Lx_s[sub] + sum_i lx_i B[i][col];  rhs lanes: the same dot gives vconst
+      vrow_own = (colv && !ct) ? pick3(sb, Lx_s[0], Lx_s[1], Lx_s[2]) : 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        double Lrow[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          double c = A[i] * Y[j] + A[6 + i] * Y[6 + j] + A[12 + i] * Y[12 + j];
+          if (ct) c += Y[i] * MiY[j] + Y[6 + i] * MiY[6 + j] + Y[12 + i] * MiY[12 + j];
+          Lrow[j] = Gs[i][j] - qo.legs_sum(c);
+        }
+        double ls = 0.0, lx = 0.0, lb = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) { ls += Lrow[j] * xdd_b[j]; lx += Lrow[j] * xdt_b[j]; lb += Lrow[j] * bcol[j]; }
+        ls += qo.legs_sum(ct ? 0.0 : Mt_bl[3 * i] * s1_s[0] + Mt_bl[3 * i + 1] * s1_s[1] + Mt_bl[3 * i + 2] * s1_s[2]);
+        lx += qo.legs_sum(ct ? 0.0 : Mt_bl[3 * i] * xdt_s[0] + Mt_bl[3 * i + 1] * xdt_s[1] + Mt_bl[3 * i + 2] * xdt_s[2]);
+        const double kp = (i < 3) ? P.Kp_body_rpy : P.Kp_body_p, kd = (i < 3) ? P.Kd_body_rpy : P.Kd_body_p;
+        const double c1 = LJ_b[i] - ls + kp * xt_b[i] + kd * xdt_b[i];
+        met_V += 0.5 * kp * xt_b[i] * xt_b[i] + 0.5 * xdt_b[i] * lx;
+        met_Vdot += -kd * xdt_b[i] * xdt_b[i] + xdt_b[i] * c1;
+        vrow_own += lx * bcol[i];
+        const double sw_term = ct ? 0.0 : pick3(sb, Mt_bl[3 * i], Mt_bl[3 * i + 1], Mt_bl[3 * i + 2]);
+        Acol[i] = colv ? sw_b * (lb + sw_term) : -sw_b * (c1 + lb);
+      }
+      vconst = qo.leg_bcast(vrow_own, 3);
+    }
+    // 12 swing rows sqrt(w_foot) [Lambda_sb a_b + Lambda_ss z_leg + c1]; zero for contact legs.
+    // Row (lp, i) is owned by lane (lp, i): its Lambda_sb row (6), c1 and Lambda_ss row (3).
+    {
+      double Msb[6], Mss[3];
+      for (int k = 0; k < 6; k++) Msb[k] = ct ? 0.0 : pick3(sb, Mt_bl[3 * k], Mt_bl[3 * k + 1], Mt_bl[3 * k + 2]);
+      for (int j = 0; j < 3; j++) Mss[j] = ct ? 0.0 : pick3(sb, Mt_ll[j], Mt_ll[3 + j], Mt_ll[6 + j]);
+      const double c1o = ct ? 0.0 : pick3(sb, c1_s[0], c1_s[1], c1_s[2]);
+#pragma unroll
+      for (int r = 0; r < NZ; r++) {
+        const int src = hex_lane(r);
+        double dotv = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) dotv += qo.bcast16(Msb[k], src) * bcol[k];
+        const double c1r = qo.bcast16(c1o, src);
+        // Lambda_ss entry (row r, own column): only within the own leg
+        const double m0 = qo.bcast16(Mss[0], src), m1 = qo.bcast16(Mss[1], src), m2 = qo.bcast16(Mss[2], src);
+        const double dg = (r / 3 == l) ? pick3(sb, m0, m1, m2) : 0.0;
+        Acol[6 + r] = colv ? sw_f * (dotv + dg) : -sw_f * (c1r + dotv);
+      }
+    }
+    hex_qr_append<Q, 18>(qo, Rcol, Acol);
+  }
+  // ---------------- level-2 rows eps (T z + t0):  T[(l',i)][(l,j)] = Y_l'[i] . B_l[:,j] + delta D_l[i][j]
+  {
+    double Acol[NZ];
+#pragma unroll
+    for (int r = 0; r < NZ; r++) {
+      const int src = hex_lane(r);
+      double dotv = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) dotv += qo.bcast16(Yrow[k], src) * bcol[k];
+      const double t0r = qo.bcast16(t0_own, src);
+      const double d0 = qo.bcast16(Drow[0], src), d1 = qo.bcast16(Drow[1], src), d2 = qo.bcast16(Drow[2], src);
+      const double dg = (r / 3 == l) ? pick3(sb, d0, d1, d2) : 0.0;
+      Acol[r] = colv ? eps * (dotv + dg) : -eps * (t0r + dotv);
+    }
+    hex_qr_append<Q, 12>(qo, Rcol, Acol);
+  }
+  // ---------------- own row of J = R^-1 and unconstrained minimiser
+  double z, Jr[NZ];
+  {
+    const double rown = [&] { double x = 0.0;
+#pragma unroll
+      for (int k = 0; k < NZ; k++) x = (hex_lane(k) == h) ? Rcol[k] : x;
+      return x; }();
+    const double inv_own = 1.0 / rown;
+    double invd[NZ];
+    double rmax = 0.0, rmin = 0.0;
+#pragma unroll
+    for (int c = 0; c < NZ; c++) {
+      invd[c] = qo.bcast16(inv_own, hex_lane(c));
+      const double a = fabs(invd[c]);   // 1/|R_cc|: max <-> min swap
+      if (c == 0 || a > rmax) rmax = a;
+      if (c == 0 || a < rmin) rmin = a;
+    }
+    // rmin/rmax here are of 1/|R_cc|:  min|R| / max|R| = rmin / rmax;  a zero pivot gives inf/nan -> singular
+    if (!(rmin > 1e-13 * rmax) || !(rmax < 1e300)) status = ST_SINGULAR;
+    if (status == ST_SINGULAR) {
+      if (colv) out_tau(m.act_inv[3 * l + sb], 0.0);
+      out_met(0, 0.0); out_met(1, met_err); out_met(2, 0.0); out_met(3, 0.0);
+      *iters_out = 0;
+      return status;
+    }
+    // my row index rr = 3*l + sb (column lanes).  J[rr][c] = (delta - sum_{k<c} J[rr][k] R[k][c]) / R[c][c]
+    const int rr = 3 * l + sb;
+    double zacc = 0.0;
+#pragma unroll
+    for (int c = 0; c < NZ; c++) {
+      double s = (colv && c == rr) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < c; k++) s -= Jr[k] * qo.bcast16(Rcol[k], hex_lane(c));
+      Jr[c] = s * invd[c];
+      zacc += Jr[c] * qo.bcast16(Rcol[c], 3);   // rhs column after the appends (lane (0,3))
+    }
+    z = zacc;
+  }
+  // ---------------- friction rows
+  int iters = 0;
+  {
+    const double s = sqrt(1.0 + mu * mu);
+    int st;
+    if (KIND == KIND_PC) {
+      const double vr = colv ? vrow_own : 0.0;
+      const double n2 = qo.sum16(vr * vr);
+      st = hex_gi(qo, h, ct, Jr, z, mu / s, 1.0 / s, sh, &iters, vr, vconst + met_Vdot, (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0);
+    } else {
+      st = hex_gi(qo, h, ct, Jr, z, mu / s, 1.0 / s, sh, &iters);
+    }
+    if (st != ST_OK) status = st;
+  }
+  *iters_out = iters;
+  // ---------------- outputs: a_b = ab0 + sum B z ;  tau_(l,j) = Y_l[j] a_b + D_l[j] z_l + t0_l[j]
+  const double z0 = qo.leg_bcast(z, 0), z1 = qo.leg_bcast(z, 1), z2 = qo.leg_bcast(z, 2);
+  {
+    double ab[6];
+    for (int i = 0; i < 6; i++) ab[i] = ab0[i] + qo.sum16(colv ? bcol[i] * z : 0.0);
+    double s = t0_own;
+    for (int k = 0; k < 6; k++) s += Yrow[k] * ab[k];
+    s += Drow[0] * z0 + Drow[1] * z1 + Drow[2] * z2;
+    if (colv) out_tau(m.act_inv[3 * l + sb], (status == ST_SINGULAR) ? 0.0 : s);
+    // generalized accelerations of the QP solution (rows 4..21 of out_met)
+    for (int i = 0; i < 6; i++) out_met(4 + i, ab[i]);
+    double t[3], y[3];
+    cross(ab, rf, t);
+    const double zl[3] = {z0, z1, z2};
+    for (int i = 0; i < 3; i++) y[i] = (ct ? bc[i] : zl[i]) - (ab[3 + i] + t[i]);
+    const double qdd = pick3(sb, Ji[0], Ji[3], Ji[6]) * y[0] + pick3(sb, Ji[1], Ji[4], Ji[7]) * y[1] + pick3(sb, Ji[2], Ji[5], Ji[8]) * y[2];
+    if (colv) out_met(4 + 6 + m.q_perm[3 * l + sb], qdd);
+  }
+  double res = 0.0;
+  if (ct) res = fmax(fabs(z0) - mu * z2, fabs(z1) - mu * z2);
+  res = fmax(0.0, qo.max16(res));
+  if (KIND != KIND_ID) {
+    met_Vdot += vconst + qo.sum16(colv ? vrow_own * z : 0.0);
+    out_met(0, met_V); out_met(1, met_err); out_met(2, 0.0); out_met(3, met_Vdot);
+  } else {
+    out_met(0, 0.0); out_met(1, met_err); out_met(2, res); out_met(3, 0.0);
+  }
+  return status;
+}
+
+}  // namespace wbc

@@ -20,6 +20,7 @@ __device__ unsigned long long g_wbc_stamps[16 * 4096];
 #include "wbc_model.hpp"
 #include "wbc_tick.hpp"
 #include "wbc_quad.hpp"
+#include "wbc_hex.hpp"
 
 namespace {
 
@@ -341,6 +342,165 @@ wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
   }
 }
 
+// ---------------------------------------------------------------- v4: 16 lanes (one DPP row) per robot
+// Static-lane broadcasts are ONE v_mov_b64_dpp row_newbcast (gfx90a+ DP-ALU DPP); reductions over the
+// four legs are row_ror:8 then row_ror:4 (after the first stage the data is 8-periodic, so the
+// rotation by 4 pairs lane h with h^4: the butterfly is commutative-symmetric and every lane ends
+// with bit-identical sums); in-leg traffic is quad_perm.
+struct HexDev {
+  int h;
+  __device__ HexDev() : h(threadIdx.x & 15) {}
+  __device__ __forceinline__ int lane() const { return h; }
+  template <int CTRL> static __device__ __forceinline__ double dpp(double x) {
+    return __builtin_amdgcn_update_dpp(0.0, x, CTRL, 0xF, 0xF, true);
+  }
+  template <int CTRL> static __device__ __forceinline__ int dppi(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+  }
+  __device__ __forceinline__ double bcast16(double x, int src) const {
+    switch (src) {
+      case 0: return dpp<0x150>(x);   case 1: return dpp<0x151>(x);   case 2: return dpp<0x152>(x);   case 3: return dpp<0x153>(x);
+      case 4: return dpp<0x154>(x);   case 5: return dpp<0x155>(x);   case 6: return dpp<0x156>(x);   case 7: return dpp<0x157>(x);
+      case 8: return dpp<0x158>(x);   case 9: return dpp<0x159>(x);   case 10: return dpp<0x15A>(x);  case 11: return dpp<0x15B>(x);
+      case 12: return dpp<0x15C>(x);  case 13: return dpp<0x15D>(x);  case 14: return dpp<0x15E>(x);  default: return dpp<0x15F>(x);
+    }
+  }
+  __device__ __forceinline__ double leg_bcast(double x, int s0) const {
+    switch (s0) {
+      case 0: return dpp<0x00>(x);
+      case 1: return dpp<0x55>(x);
+      case 2: return dpp<0xAA>(x);
+      default: return dpp<0xFF>(x);
+    }
+  }
+  __device__ __forceinline__ double leg_sum(double x) const {
+    x += dpp<0xB1>(x);
+    x += dpp<0x4E>(x);
+    return x;
+  }
+  __device__ __forceinline__ double legs_sum(double x) const {
+    x += dpp<0x128>(x);  // row_ror:8
+    x += dpp<0x124>(x);  // row_ror:4
+    return x;
+  }
+  __device__ __forceinline__ double sum16(double x) const { return legs_sum(leg_sum(x)); }
+  __device__ __forceinline__ double max16(double x) const {
+    x = fmax(x, dpp<0xB1>(x));
+    x = fmax(x, dpp<0x4E>(x));
+    x = fmax(x, dpp<0x128>(x));
+    x = fmax(x, dpp<0x124>(x));
+    return x;
+  }
+  __device__ __forceinline__ bool any16(bool b) const {
+    int x = b ? 1 : 0;
+    x |= dppi<0xB1>(x);
+    x |= dppi<0x4E>(x);
+    x |= dppi<0x128>(x);
+    x |= dppi<0x124>(x);
+    return x != 0;
+  }
+  __device__ __forceinline__ void argmin16(double& v, int& i) const {
+    QuadDev::amin(v, i, dpp<0xB1>(v), dppi<0xB1>(i));
+    QuadDev::amin(v, i, dpp<0x4E>(v), dppi<0x4E>(i));
+    QuadDev::amin(v, i, dpp<0x128>(v), dppi<0x128>(i));
+    QuadDev::amin(v, i, dpp<0x124>(v), dppi<0x124>(i));
+  }
+  __device__ __forceinline__ bool wave_all(bool b) const { return __all(b); }
+  __device__ __forceinline__ int wave_max_int(int x) const {
+    int m = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) m |= (__any((x >> b) & 1) ? 1 : 0) << b;
+    return m;
+  }
+};
+
+constexpr int HROBOTS = BLOCK / 16;  // robots per 64-lane block
+
+template <int KIND>
+__global__ void __launch_bounds__(BLOCK)
+wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld,
+               const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
+               const uint8_t* __restrict__ mask, const double* __restrict__ mu,
+               const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
+               int32_t* __restrict__ status, StatsDev* __restrict__ stats, double* __restrict__ vdot) {
+  __shared__ double mbuf[MODEL_PAD_WORDS];
+  __shared__ double inbuf[NIN * HROBOTS];
+  __shared__ wbc::QuadShared shq[HROBOTS];
+  const int slot = threadIdx.x >> 4;
+  const int i = blockIdx.x * HROBOTS + slot;
+  const bool live = i < n;
+  const int ii = live ? i : (n - 1);
+  {
+    // model table: batched copy from a per-block replica (see wbc_quad_kernel)
+    const double* src = reinterpret_cast<const double*>(mp) + (size_t)(blockIdx.x % MODEL_REPLICAS) * MODEL_PAD_WORDS;
+    double t[MODEL_PAD_WORDS / BLOCK];
+#pragma unroll
+    for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) t[j] = src[j * BLOCK + threadIdx.x];
+    // inputs: 91 rows x 4 robots, 6 independent loads per lane
+    constexpr int PER_LANE = (NIN * HROBOTS + BLOCK - 1) / BLOCK;
+    double tmp[PER_LANE];
+    const int r0 = blockIdx.x * HROBOTS;
+#pragma unroll
+    for (int j = 0; j < PER_LANE; j++) {
+      const int idx = j * BLOCK + threadIdx.x;
+      const int row = idx / HROBOTS, sl = idx % HROBOTS;
+      const int rob = min(r0 + sl, n - 1);
+      const double* srow = row < 19 ? q + (size_t)row * ld : (row < 37 ? v + (size_t)(row - 19) * ld : tg + (size_t)(row - 37) * ld);
+      tmp[j] = (idx < NIN * HROBOTS) ? srow[rob] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) mbuf[j * BLOCK + threadIdx.x] = t[j];
+#pragma unroll
+    for (int j = 0; j < PER_LANE; j++) {
+      const int idx = j * BLOCK + threadIdx.x;
+      if (idx < NIN * HROBOTS) inbuf[idx] = tmp[j];
+    }
+    __syncthreads();
+  }
+  const wbc::ModelC& m = *reinterpret_cast<const wbc::ModelC*>(mbuf);
+  const wbc::ParamsC& P = *pp;
+  HexDev qo;
+  auto in = [&](int r) -> double { return inbuf[r * HROBOTS + slot]; };
+  double tsum = 0.0, tmax = 0.0, errv = 0.0;
+  auto ot = [&](int k, double x) {
+    if (live) tau[(size_t)k * ld + ii] = x;
+    tsum += fabs(x);
+    tmax = fmax(tmax, fabs(x));
+  };
+  const bool lead = qo.h == 0;
+  auto om = [&](int k, double x) {   // rows 0..3: metrics (lead lane), rows 4..9: base accelerations (lead), 10..21: own joint
+    if (k >= 4) {
+      if (live && vdot && (k >= 10 || lead)) vdot[(size_t)(k - 4) * ld + ii] = x;
+      return;
+    }
+    if (live && lead && met) met[(size_t)k * ld + ii] = x;
+    if (k == 1) errv = x;
+  };
+  const unsigned mk = mask[ii] & 0xF;
+  const double mui = mu ? mu[ii] : P.mu;
+  const double msi = ms ? ms[ii] : 1.0;
+  int iters = 0;
+  const int st = wbc::hex_tick<HexDev, KIND>(m, P, qo, in, mk, mui, msi, shq[slot], ot, om, &iters);
+  if (live && lead && status) status[ii] = st;
+  if (stats) {
+    const double lv = (live && lead) ? 1.0 : 0.0, la = live ? 1.0 : 0.0;
+    double a = wave_sum(lv), b = wave_sum((live && lead && st != 0) ? 1.0 : 0.0), c = wave_sum(lv * iters);
+    double d = wave_sum(la * tsum), e = wave_max(la * tmax), f = wave_sum(lv * errv);
+    unsigned long long bal[16];
+    for (int k = 0; k < 16; k++) bal[k] = __ballot(live && lead && mk == (unsigned)k);
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&stats->ticks, a);
+      if (b != 0.0) atomicAdd(&stats->status_nonzero, b);
+      atomicAdd(&stats->iters_sum, c);
+      atomicAdd(&stats->tau_abs_sum, d);
+      atomicMax(&stats->tau_abs_max_bits, (unsigned long long)__double_as_longlong(e));
+      atomicAdd(&stats->err_sum, f);
+      for (int k = 0; k < 16; k++)
+        if (bal[k]) atomicAdd(&stats->mask_count[k], (double)__popcll(bal[k]));
+    }
+  }
+}
+
 // ---------------------------------------------------------------- forward step
 // Semi-implicit Euler in the reference's coordinates: v = [w_WB (world); v_WBo (world); qd].
 __global__ void wbc_integrate_kernel(int n, int ld, double dt, double* __restrict__ q, double* __restrict__ v,
@@ -496,6 +656,7 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
                   int32_t* status) {
   // variant 0 = auto: the quad kernel (4 lanes per robot) unless the optional torque box is on,
   // which only the lane-per-robot kernel implements.
+  const bool hex = (h->variant == 3);
   const bool quad = (h->variant == 2) || (h->variant == 0 && !h->lane_only);
   dim3 block(BLOCK);
   StatsDev* d_stats = getenv("WBC_NO_STATS") ? nullptr : h->d_stats;  // diagnostic switch
@@ -515,7 +676,10 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
                            mask, mu, ms, tau, met, status, d_stats, h->d_vdot);                                         \
     }                                                                                                        \
   } while (0)
-  if (quad) {
+  if (hex) {
+    dim3 grid((n + HROBOTS - 1) / HROBOTS);
+    WBC_LAUNCH(wbc_hex_kernel, grid);
+  } else if (quad) {
     dim3 grid((n + QROBOTS - 1) / QROBOTS);
     WBC_LAUNCH(wbc_quad_kernel, grid);
   } else if (h->kind == WBC_KIND_CLF) {
@@ -669,8 +833,8 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
 
 int wbc_set_variant(wbc_handle h, int variant) {
   if (!h) return misuse("wbc_set_variant: null handle");
-  if (variant < 0 || variant > 2) return misuse("wbc_set_variant: 0 = auto, 1 = lane-per-robot, 2 = quad-per-robot");
-  if (variant == 2 && h->lane_only) return misuse("wbc_set_variant: the quad kernel has no torque box / CLF law");
+  if (variant < 0 || variant > 3) return misuse("wbc_set_variant: 0 = auto, 1 = lane-per-robot, 2 = quad-per-robot, 3 = 16 lanes per robot");
+  if (variant >= 2 && h->lane_only) return misuse("wbc_set_variant: the quad kernel has no torque box / CLF law");
   h->variant = variant;
   return 0;
 }
@@ -680,7 +844,9 @@ int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_by
   hipFuncAttributes a;
   const bool quad = (h->variant == 2) || (h->variant == 0 && !h->lane_only);
   const void* fn;
-  if (quad) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_quad_kernel<wbc::KIND_ID>
+  if (h->variant == 3) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID>
+               : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_kernel<wbc::KIND_MPTC> : (const void*)wbc_hex_kernel<wbc::KIND_PC>;
+  else if (quad) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_quad_kernel<wbc::KIND_ID>
                : h->kind == WBC_KIND_MPTC ? (const void*)wbc_quad_kernel<wbc::KIND_MPTC> : (const void*)wbc_quad_kernel<wbc::KIND_PC>;
   else fn = h->kind == WBC_KIND_ID ? (const void*)wbc_tick_kernel<wbc::KIND_ID>
           : h->kind == WBC_KIND_MPTC ? (const void*)wbc_tick_kernel<wbc::KIND_MPTC>

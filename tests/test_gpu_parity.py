@@ -30,7 +30,7 @@ def gpu_step(kind, model, q, v, tg, mask, mu=None, ms=None, params=None, max_bat
     cls = {"id": IDController, "mptc": MPTCController, "pc": PCController, "clf": CLFController}[kind]
     n = q.shape[1]
     ctrl = cls(model=model, max_batch=max_batch or n, device=0, params=params, **kw)
-    if not (kind == "clf" and variant == "quad"):       # CLF exists on the lane kernel only
+    if not (kind == "clf" and variant in ("quad", "hex")):       # CLF exists on the lane kernel only
         ctrl.set_variant(variant)
     up = lambda x: None if x is None else torch.tensor(np.ascontiguousarray(x), device="cuda:0")
     tau, met, st = ctrl.step(up(q), up(v), up(tg), up(mask), up(mu), up(ms))
@@ -58,7 +58,7 @@ def test_native_library_is_the_one_loaded():
         assert "libwbc_hip.so" in f.read()
 
 
-@pytest.mark.parametrize("variant", ["quad", "lane"])
+@pytest.mark.parametrize("variant", ["hex", "quad", "lane"])
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
 def test_gpu_matches_golden_vectors(path, variant):
     g = load_gold(path)
@@ -69,7 +69,7 @@ def test_gpu_matches_golden_vectors(path, variant):
     assert np.allclose(met, g["metrics"], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("variant", ["quad", "lane"])
+@pytest.mark.parametrize("variant", ["hex", "quad", "lane"])
 @pytest.mark.parametrize("cfg,kind,n", [(2, "id", 1024), (3, "mptc", 2048), (4, "mptc", 1024), (5, "mptc", 1024), (3, "id", 512),
                                         (3, "pc", 1024), (2, "pc", 256), (3, "clf", 512), (2, "clf", 256)])
 def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n, variant):
@@ -92,12 +92,13 @@ def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n, variant):
     assert stats["mask_count"] == [float((b["mask"] == k).sum()) for k in range(16)]
 
 
-@pytest.mark.parametrize("n", [1, 15, 16, 17, 63, 64, 65, 200])
-def test_ragged_batch_sizes(n):
+@pytest.mark.parametrize("variant", ["hex", "quad"])
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 200])
+def test_ragged_batch_sizes(n, variant):
     from oracle import oracle_py as orc
     from quadruped_drake_amd import workloads
     b = workloads.make_batch(3, n=n)
-    tau, met, st, _ = gpu_step("mptc", b["model"], b["q"], b["v"], b["targets"], b["mask"], max_batch=256)
+    tau, met, st, _ = gpu_step("mptc", b["model"], b["q"], b["v"], b["targets"], b["mask"], max_batch=256, variant=variant)
     tau_o, _, _ = orc.step_batch("mptc", orc.model(b["model"]), orc.params("mptc"), b["q"], b["v"], b["targets"], b["mask"])
     assert tau.shape == (12, n) and (st == 0).all()
     assert rel_err(tau, tau_o).max() < TOL

@@ -210,3 +210,165 @@ extern "C" int host_quad_batch(int kind, const double* flat215, const double* pa
   for (auto& t : th) t.join();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Host emulation of the 16-lanes-per-robot kernel (wbc_hex.hpp): 16 cooperative fibres (ucontext,
+// one OS thread, round-robin) play the 16 lanes of a DPP row; every cross-lane op is
+// "publish, barrier, read, barrier".  The reductions use the association of the device butterflies
+// (quad_perm xor 1, xor 2, then row_ror:8, row_ror:4), so replicated values are bit-identical.
+#include <ucontext.h>
+#include "../quadruped_drake_amd/csrc/wbc_hex.hpp"
+
+namespace {
+struct HexCtx {
+  double slot[16];
+  int islot[16];
+  int count = 0;
+  unsigned gen = 0;
+  ucontext_t ctx[16], main;
+  bool finished[16];
+  int cur = 0;
+  void (*body)(int) = nullptr;
+};
+HexCtx* g_hex = nullptr;
+
+void hex_switch_from(int me) {
+  HexCtx* c = g_hex;
+  for (int d = 1; d <= 16; d++) {
+    const int nx = (me + d) % 16;
+    if (!c->finished[nx]) {
+      if (nx == me) return;
+      c->cur = nx;
+      swapcontext(&c->ctx[me], &c->ctx[nx]);
+      return;
+    }
+  }
+  swapcontext(&c->ctx[me], &c->main);  // everybody finished
+}
+void hex_barrier(int me) {
+  HexCtx* c = g_hex;
+  const unsigned g = c->gen;
+  if (++c->count == 16) { c->count = 0; c->gen++; return; }
+  while (c->gen == g) hex_switch_from(me);
+}
+void hex_entry(int lane) {
+  HexCtx* c = g_hex;
+  c->body(lane);
+  hex_barrier(lane);  // all lanes leave together
+  c->finished[lane] = true;
+  hex_switch_from(lane);
+}
+}  // namespace
+
+struct HexHost {
+  int h;
+  int lane() const { return h; }
+  double xchg(double x, int src) {
+    g_hex->slot[h] = x; hex_barrier(h);
+    const double r = g_hex->slot[src]; hex_barrier(h);
+    return r;
+  }
+  double bcast16(double x, int src) { return xchg(x, src); }
+  double leg_bcast(double x, int s0) { return xchg(x, (h & ~3) | s0); }
+  static double quad_of(const double* s, int b) { return (s[b] + s[b ^ 1]) + (s[b ^ 2] + s[b ^ 3]); }
+  double leg_sum(double x) {
+    g_hex->slot[h] = x; hex_barrier(h);
+    const double r = quad_of(g_hex->slot, h); hex_barrier(h);
+    return r;
+  }
+  double legs_sum(double x) {
+    g_hex->slot[h] = x; hex_barrier(h);
+    const double* s = g_hex->slot;
+    const double r = (s[h] + s[h ^ 8]) + (s[h ^ 4] + s[h ^ 12]); hex_barrier(h);
+    return r;
+  }
+  double sum16(double x) {
+    g_hex->slot[h] = x; hex_barrier(h);
+    const double* s = g_hex->slot;
+    const double r = (quad_of(s, h) + quad_of(s, h ^ 8)) + (quad_of(s, h ^ 4) + quad_of(s, h ^ 12)); hex_barrier(h);
+    return r;
+  }
+  double max16(double x) {
+    g_hex->slot[h] = x; hex_barrier(h);
+    double r = g_hex->slot[0];
+    for (int k = 1; k < 16; k++) r = fmax(r, g_hex->slot[k]);
+    hex_barrier(h);
+    return r;
+  }
+  bool any16(bool b) {
+    g_hex->islot[h] = b; hex_barrier(h);
+    bool r = false;
+    for (int k = 0; k < 16; k++) r |= (g_hex->islot[k] != 0);
+    hex_barrier(h);
+    return r;
+  }
+  void argmin16(double& v, int& i) {
+    g_hex->slot[h] = v; g_hex->islot[h] = i; hex_barrier(h);
+    double bv = g_hex->slot[0]; int bi = g_hex->islot[0];
+    for (int k = 1; k < 16; k++) {
+      const double ov = g_hex->slot[k]; const int oi = g_hex->islot[k];
+      if (ov < bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; }
+    }
+    hex_barrier(h);
+    v = bv; i = bi;
+  }
+  bool wave_all(bool b) { return b; }
+  int wave_max_int(int x) { return x; }
+};
+
+extern "C" int host_hex_batch(int kind, const double* flat215, const double* params12, const int* q_perm,
+                              const int* act_perm, int n, int stride, const double* q, const double* v,
+                              const double* tg, const unsigned char* mask, const double* mu,
+                              const double* mass_scale, double* tau, double* met, int* status, int* iters) {
+  static wbc::ModelC m;
+  static wbc::ParamsC P;
+  if (wbc::model_from_flat(flat215, &m)) return -1;
+  wbc::model_set_perms(&m, q_perm, act_perm);
+  wbc::params_default(kind, &P);
+  if (params12) memcpy(&P, params12, sizeof(double) * 12);
+  static HexCtx ctx;
+  g_hex = &ctx;
+  const size_t STK = 1 << 20;
+  static std::vector<char> stacks(16 * STK);
+  static wbc::QuadShared sh[16];  // replicated per lane on the host (shared LDS with replicated writes on the device)
+  struct Args { int kind, i, stride; const double *q, *v, *tg, *mu, *ms; const unsigned char* mask; double *tau, *met; int *status, *iters; };
+  static Args A;
+  A = Args{kind, 0, stride, q, v, tg, mu, mass_scale, mask, tau, met, status, iters};
+  ctx.body = [](int h) {
+    const Args& a = A;
+    const int i = a.i;
+    HexHost qo{h};
+    auto in = [&](int r) -> double {
+      if (r < 19) return a.q[(size_t)r * a.stride + i];
+      if (r < 37) return a.v[(size_t)(r - 19) * a.stride + i];
+      return a.tg[(size_t)(r - 37) * a.stride + i];
+    };
+    auto ot = [&](int k, double x) { a.tau[(size_t)k * a.stride + i] = x; };
+    auto om = [&](int k, double x) {
+      if (k >= 4) { if (g_vdot && (k >= 10 || h == 0)) g_vdot[(size_t)(k - 4) * a.stride + i] = x; return; }
+      if (h == 0 && a.met) a.met[(size_t)k * a.stride + i] = x;
+    };
+    int it = 0, st;
+    const double mui = a.mu ? a.mu[i] : P.mu, msi = a.ms ? a.ms[i] : 1.0;
+    if (a.kind == wbc::KIND_ID) st = wbc::hex_tick<HexHost, wbc::KIND_ID>(m, P, qo, in, a.mask[i], mui, msi, sh[h], ot, om, &it);
+    else if (a.kind == wbc::KIND_PC) st = wbc::hex_tick<HexHost, wbc::KIND_PC>(m, P, qo, in, a.mask[i], mui, msi, sh[h], ot, om, &it);
+    else st = wbc::hex_tick<HexHost, wbc::KIND_MPTC>(m, P, qo, in, a.mask[i], mui, msi, sh[h], ot, om, &it);
+    if (h == 0) { if (a.status) a.status[i] = st; if (a.iters) a.iters[i] = it; }
+  };
+  for (int i = 0; i < n; i++) {
+    A.i = i;
+    memset(sh, 0, sizeof sh);
+    ctx.count = 0;
+    for (int h = 0; h < 16; h++) {
+      ctx.finished[h] = false;
+      getcontext(&ctx.ctx[h]);
+      ctx.ctx[h].uc_stack.ss_sp = stacks.data() + (size_t)h * STK;
+      ctx.ctx[h].uc_stack.ss_size = STK;
+      ctx.ctx[h].uc_link = &ctx.main;
+      makecontext(&ctx.ctx[h], (void (*)())hex_entry, 1, h);
+    }
+    ctx.cur = 0;
+    swapcontext(&ctx.main, &ctx.ctx[0]);
+  }
+  return 0;
+}
