@@ -123,6 +123,7 @@ def main():
 
     if rank == 0:
         status = out[2].cpu().numpy()
+        used = ctrl.variant_for(n)            # "auto" resolves by batch size (include/wbc.h)
         key = (shard["kind"], cfg)
         flops = FLOPS_PER_TICK.get(key, 37629.0)
         bpt = BYTES_PER_TICK[mu is not None]
@@ -134,7 +135,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
                 tr = json.load(f)
-            ent = tr.get("%s_cfg%d_n%d_%s" % (shard["kind"], cfg, n, a.variant if a.variant in ("lane", "hex") else "quad"))
+            ent = tr.get("%s_cfg%d_n%d_%s" % (shard["kind"], cfg, n, used))
             if ent:
                 traffic = ent["bytes_per_launch"]
         except (OSError, ValueError):
@@ -152,7 +153,7 @@ def main():
                 "domain_randomised": mu is not None, "parallelism": "batch-shard x%d" % world},
             "roofline": {"bound": "valu-f64", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "%s<%s>" % ({"lane": "wbc_tick_kernel", "hex": "wbc_hex_kernel"}.get(a.variant, "wbc_quad_kernel"), shard["kind"].upper()),
+                         "kernel": "%s<%s>" % ({"lane": "wbc_tick_kernel", "hex": "wbc_hex_kernel", "quad": "wbc_quad_kernel"}[used], shard["kind"].upper()),
                          "kernel_ms": ms_per_launch, "flops_per_tick": flops,
                          "hbm": {"achieved_GBs": bpt * n / sec / 1e9, "peak_GBs": PEAK_HBM_GBS,
                                  "frac": bpt * n / sec / 1e9 / PEAK_HBM_GBS, "bytes_per_tick": bpt},

@@ -147,12 +147,16 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
                 double* time, double* targets, uint8_t* contact_mask, const double* mu,
                 const double* mass_scale, double* tau, double* metrics, int32_t* status, double* vdot);
 
-/* Kernel variant: 0 = auto (default), 1 = lane-per-robot, 2 = quad-per-robot (4 lanes = 4 legs).
- * Both compute the same tick; auto picks quad unless the optional torque box is enabled or the
- * kind is WBC_KIND_CLF (13 reduced variables: lane kernel only). */
+/* Kernel variant: 0 = auto (default), 1 = lane-per-robot, 2 = quad-per-robot (4 lanes = 4 legs),
+ * 3 = 16 lanes (one DPP row) per robot.  All compute the same tick.  Auto picks by batch size:
+ * 16-lane while n/4 wavefronts fit one (ID) / two (MPTC, PC) per SIMD, quad beyond; lane-per-robot
+ * when the optional torque box is enabled or the kind is WBC_KIND_CLF (13 reduced variables). */
 int wbc_set_variant(wbc_handle h, int variant);
+/* The variant (1, 2 or 3) a wbc_step of n instances would run. */
+int wbc_variant_for(wbc_handle h, int n);
 
-/* Kernel resource report for the handle's kind: registers, scratch bytes/lane, LDS bytes. */
+/* Kernel resource report for the variant of the most recent launch (or of max_batch before any):
+ * registers, scratch bytes/lane, LDS bytes. */
 int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads);
 
 /* ------------------------------------------------------------------------------------------

@@ -201,6 +201,13 @@ class BatchedController:
         v = {"auto": 0, "lane": 1, "quad": 2, "hex": 3}.get(variant, variant)
         _lib.check(self._L.wbc_set_variant(self._h, int(v)))
 
+    def variant_for(self, n):
+        """Name of the kernel variant a step of n instances runs ("lane", "quad" or "hex")."""
+        v = self._L.wbc_variant_for(self._h, int(n))
+        if v < 0:
+            _lib.check(v)
+        return {1: "lane", 2: "quad", 3: "hex"}[v]
+
     def kernel_info(self):
         a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         _lib.check(self._L.wbc_kernel_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))

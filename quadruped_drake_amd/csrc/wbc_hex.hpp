@@ -201,14 +201,25 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   return status;
 }
 
+// Robot-level cold storage ("park"): replicated values that are produced early and consumed late
+// (G_b for the MPTC rows) wait in LDS instead of occupying 2 VGPRs each -- a spilled VGPR costs an
+// exposed L2 round trip (~0.4 us measured, profiles/r02), an LDS read ~100 cycles.  All 16 lanes
+// write the same value to the same address.  Host: a plain array.
+enum { PK_GS = 0, PK_N = 36 };
+struct ParkHost {
+  double d[PK_N];
+  void put(int i, double v) { d[i] = v; }
+  double get(int i) const { return d[i]; }
+};
+
 // per-lane pick of element `sb` (0..2) of a replicated triple
 WBC_HD double pick3(int sb, double a, double b, double c) { return (sb == 0) ? a : ((sb == 1) ? b : c); }
 
 // The tick.  Every lane of the row calls this with its own Q (lane id h = 4*leg + sub).
 // out_tau(row, x): lane (leg, j<3) writes the torque of joint 3*leg+j;  out_met: see the kernel.
-template <class Q, int KIND, class In, class OutTau, class OutMet>
+template <class Q, int KIND, class Park, class In, class OutTau, class OutMet>
 WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned mask, double mu, double mass_scale,
-                    QuadShared& sh, OutTau out_tau, OutMet out_met, int* iters_out) {
+                    QuadShared& sh, Park& pk, OutTau out_tau, OutMet out_met, int* iters_out) {
   const int h = qo.lane();
   const int l = h >> 2, sb = h & 3;
   const bool ct = (mask >> l) & 1u;
@@ -443,6 +454,9 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       Gs[i][4] = Mbb[i][4] - qo.legs_sum(a1);
       Gs[i][5] = Mbb[i][5] - qo.legs_sum(a2);
     }
+    if (KIND != KIND_ID)
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) pk.put(PK_GS + 6 * i + j, Gs[i][j]);
   }
   // own column of [B | ab0]:  G_b bcol = (W_l or -X_l)[:, sub]  (sub < 3)  |  -kv  (sub == 3)
   double bcol[6], ab0[6];
@@ -473,7 +487,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   met_err += qo.legs_sum(xt_s[0] * xt_s[0] + xt_s[1] * xt_s[1] + xt_s[2] * xt_s[2]);
   double met_V = 0.0, met_Vdot = 0.0;
   double vrow_own = 0.0, vconst = 0.0;  // Vdot = met_Vdot + vconst + sum over column lanes of vrow_own * z
-  {
+  auto init_rcol = [&]()   {
     // diagonal rows: swing leg sqrt(w_foot) (ID) / 0 (MPTC); contact leg eps.  Row 3*leg+sub lives on lane (leg, sub).
     double dval, drhs;
     const double xdd_o = pick3(sb, xdd_s[0], xdd_s[1], xdd_s[2]), xt_o = pick3(sb, xt_s[0], xt_s[1], xt_s[2]),
@@ -488,10 +502,11 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       const double rk = qo.bcast16(drhs, hex_lane(k));
       Rcol[k] = colv ? ((hex_lane(k) == h) ? dval : 0.0) : rk;
     }
-  }
+  };
   if (KIND == KIND_ID) {
     double Acol[6];
     for (int i = 0; i < 6; i++) Acol[i] = colv ? sw_b * bcol[i] : sw_b * (ades[i] - bcol[i]);
+    init_rcol();
     hex_qr_append<Q, 6>(qo, Rcol, Acol);
   } else {
     // ---- MPTC in task coordinates (derivation: wbc_tick.hpp / DESIGN.md)
@@ -574,7 +589,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
         for (int j = 0; j < 6; j++) {
           double c = A[i] * Y[j] + A[6 + i] * Y[6 + j] + A[12 + i] * Y[12 + j];
           if (ct) c += Y[i] * MiY[j] + Y[6 + i] * MiY[6 + j] + Y[12 + i] * MiY[12 + j];
-          Lrow[j] = Gs[i][j] - qo.legs_sum(c);
+          Lrow[j] = pk.get(PK_GS + 6 * i + j) - qo.legs_sum(c);
         }
         double ls = 0.0, lx = 0.0, lb = 0.0;
 #pragma unroll
@@ -611,6 +626,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
         Acol[6 + r] = colv ? sw_f * (dotv + dg) : -sw_f * (c1r + dotv);
       }
     }
+    init_rcol();
     hex_qr_append<Q, 18>(qo, Rcol, Acol);
   }
   // ---------------- level-2 rows eps (T z + t0):  T[(l',i)][(l,j)] = Y_l'[i] . B_l[:,j] + delta D_l[i][j]

@@ -48,6 +48,11 @@ struct StatsDev {
 };
 
 constexpr int BLOCK = 64;
+// The end-of-rollout statistics are accumulated with fire-and-forget atomics into one of STAT_SLOTS
+// per-block slots: 22 atomics per wavefront on ONE address set serialise in L2 (measured: +50 us at
+// 1024 wavefronts, profiles/r02); spread over slots they pipeline.  wbc_stats_get reduces the slots.
+constexpr int STAT_SLOTS = 2048;
+static_assert(sizeof(StatsDev) == 22 * 8, "StatsDev is 22 eight-byte words (wbc_stats_reduce_kernel)");
 
 __device__ __forceinline__ double wave_sum(double x) {
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -93,6 +98,7 @@ wbc_tick_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
   const int st = wbc::tick<double, KIND>(m, P, in, mk, mui, msi, ot, om, &iters);
   if (live && status) status[ii] = st;
   if (stats) {
+    stats += blockIdx.x & (STAT_SLOTS - 1);
     const double lv = live ? 1.0 : 0.0;
     double a = wave_sum(lv), b = wave_sum(live && st != 0 ? 1.0 : 0.0), c = wave_sum(lv * iters);
     double d = wave_sum(lv * tsum), e = wave_max(lv * tmax), f = wave_sum(lv * errv);
@@ -324,6 +330,7 @@ wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restri
   WBC_STAMP(14);
   if (live && lead && status) status[ii] = st;
   if (stats) {
+    stats += blockIdx.x & (STAT_SLOTS - 1);
     const double lv = (live && lead) ? 1.0 : 0.0, la = live ? 1.0 : 0.0;
     double a = wave_sum(lv), b = wave_sum((live && lead && st != 0) ? 1.0 : 0.0), c = wave_sum(lv * iters);
     double d = wave_sum(la * tsum), e = wave_max(la * tmax), f = wave_sum(lv * errv);
@@ -415,6 +422,20 @@ struct HexDev {
 };
 
 constexpr int HROBOTS = BLOCK / 16;  // robots per 64-lane block
+// robot-level park in LDS (wbc_hex.hpp): reads go through a laundered pointer so that the compiler
+// cannot forward the stored values (i.e. keep them in registers / spill them) yet the loads stay
+// ordinary, schedulable LDS loads
+struct ParkLds {
+  double* a;
+  const double* r;
+  __device__ __forceinline__ explicit ParkLds(double* p) : a(p) {
+    const double* q = p;
+    asm volatile("" : "+v"(q));
+    r = q;
+  }
+  __device__ __forceinline__ void put(int i, double v) { a[i] = v; }
+  __device__ __forceinline__ double get(int i) const { return r[i]; }
+};
 
 template <int KIND>
 __global__ void __launch_bounds__(BLOCK)
@@ -426,6 +447,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   __shared__ double mbuf[MODEL_PAD_WORDS];
   __shared__ double inbuf[NIN * HROBOTS];
   __shared__ wbc::QuadShared shq[HROBOTS];
+  __shared__ double parkbuf[HROBOTS * wbc::PK_N];
   const int slot = threadIdx.x >> 4;
   const int i = blockIdx.x * HROBOTS + slot;
   const bool live = i < n;
@@ -480,9 +502,18 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   const double mui = mu ? mu[ii] : P.mu;
   const double msi = ms ? ms[ii] : 1.0;
   int iters = 0;
-  const int st = wbc::hex_tick<HexDev, KIND>(m, P, qo, in, mk, mui, msi, shq[slot], ot, om, &iters);
+#ifdef WBC_FORCE_SCRATCH   // diagnostic: give the kernel a private segment without changing its math
+  volatile double junk[WBC_FORCE_SCRATCH];
+  for (int k = 0; k < WBC_FORCE_SCRATCH; k++) junk[k] = inbuf[k];
+#endif
+  ParkLds park(parkbuf + slot * wbc::PK_N);
+  const int st = wbc::hex_tick<HexDev, KIND>(m, P, qo, in, mk, mui, msi, shq[slot], park, ot, om, &iters);
+#ifdef WBC_FORCE_SCRATCH
+  if (junk[threadIdx.x % WBC_FORCE_SCRATCH] == 1.2345e300) iters++;
+#endif
   if (live && lead && status) status[ii] = st;
   if (stats) {
+    stats += blockIdx.x & (STAT_SLOTS - 1);
     const double lv = (live && lead) ? 1.0 : 0.0, la = live ? 1.0 : 0.0;
     double a = wave_sum(lv), b = wave_sum((live && lead && st != 0) ? 1.0 : 0.0), c = wave_sum(lv * iters);
     double d = wave_sum(la * tsum), e = wave_max(la * tmax), f = wave_sum(lv * errv);
@@ -531,6 +562,20 @@ __global__ void wbc_integrate_kernel(int n, int ld, double dt, double* __restric
   for (int r = 0; r < 12; r++) q[(size_t)(7 + r) * ld + i] += dt * vn[6 + r];
 }
 
+// slot 0 <- sum / max over all slots (one block of 64 lanes)
+__global__ void wbc_stats_reduce_kernel(StatsDev* __restrict__ st, StatsDev* __restrict__ out) {
+  constexpr int NW = sizeof(StatsDev) / 8;  // 22 words; word 4 is the max (bit pattern of a non-negative double)
+  for (int w = 0; w < NW; w++) {
+    double acc = 0.0;
+    for (int sl = threadIdx.x; sl < STAT_SLOTS; sl += 64) {
+      const double x = reinterpret_cast<const double*>(st + sl)[w];
+      acc = (w == 4) ? fmax(acc, x) : acc + x;
+    }
+    acc = (w == 4) ? wave_max(acc) : wave_sum(acc);
+    if (threadIdx.x == 0) reinterpret_cast<double*>(out)[w] = acc;
+  }
+}
+
 __global__ void wbc_advance_time_kernel(int n, double dt, double* __restrict__ time) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) time[i] += dt;
@@ -540,6 +585,7 @@ __global__ void wbc_advance_time_kernel(int n, double dt, double* __restrict__ t
 
 struct wbc_handle_s {
   int kind, max_batch, device, variant;
+  int last_variant;  // kernel used by the most recent launch (1 lane, 2 quad, 3 hex)
   bool torque_box, lane_only;
   uint32_t flags;
   hipStream_t stream;
@@ -601,7 +647,7 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
   h->own_stream = true;
   HIP_TRY(hipMalloc(&h->d_model, (size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8));
   HIP_TRY(hipMalloc(&h->d_params, sizeof P));
-  HIP_TRY(hipMalloc(&h->d_stats, sizeof(StatsDev)));
+  HIP_TRY(hipMalloc(&h->d_stats, sizeof(StatsDev) * (STAT_SLOTS + 1)));
   {
     // MODEL_REPLICAS padded copies (the lane-per-robot kernel reads replica 0 through a ModelC*)
     char* rep = new char[(size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8]();
@@ -611,7 +657,7 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
     if (e != hipSuccess) return fail("hipMemcpy(model replicas)", e);
   }
   HIP_TRY(hipMemcpy(h->d_params, &P, sizeof P, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(h->d_stats, 0, sizeof(StatsDev)));
+  HIP_TRY(hipMemset(h->d_stats, 0, sizeof(StatsDev) * (STAT_SLOTS + 1)));
   HIP_TRY(hipEventCreate(&h->ev0));
   HIP_TRY(hipEventCreate(&h->ev1));
   if (flags & WBC_HOST_PTRS) {
@@ -651,13 +697,26 @@ int wbc_set_stream(wbc_handle h, void* hip_stream) {
   return 0;
 }
 
+// variant 0 = auto.  Measured on MI355X (profiles/r02/sweep.md): the 16-lane kernel wins while its n/4
+// wavefronts fit one (ID: GI-bound) or two (MPTC/PC) per SIMD of the 256 CUs; beyond that the quad
+// kernel's lower total instruction count wins.  The torque box and the CLF law exist on the
+// lane-per-robot kernel only.
+static int pick_variant(const wbc_handle_s* h, int n) {
+  if (h->variant) return h->variant;
+  if (h->lane_only) return 1;
+  const int hex_waves = (n + 3) / 4;
+  const int limit = 1024 * (h->kind == WBC_KIND_ID ? 1 : 2);
+  return hex_waves <= limit ? 3 : 2;
+}
+
 static int launch(wbc_handle h, int n, int ld, const double* q, const double* v, const double* tg,
                   const uint8_t* mask, const double* mu, const double* ms, double* tau, double* met,
                   int32_t* status) {
   // variant 0 = auto: the quad kernel (4 lanes per robot) unless the optional torque box is on,
   // which only the lane-per-robot kernel implements.
-  const bool hex = (h->variant == 3);
-  const bool quad = (h->variant == 2) || (h->variant == 0 && !h->lane_only);
+  const int var = pick_variant(h, n);
+  h->last_variant = var;
+  const bool hex = (var == 3), quad = (var == 2);
   dim3 block(BLOCK);
   StatsDev* d_stats = getenv("WBC_NO_STATS") ? nullptr : h->d_stats;  // diagnostic switch
 #define WBC_LAUNCH(KERNEL, GRID)                                                                              \
@@ -764,7 +823,10 @@ int wbc_stats_get(wbc_handle h, wbc_stats* out) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   StatsDev s;
-  HIP_TRY(hipMemcpy(&s, h->d_stats, sizeof s, hipMemcpyDeviceToHost));
+  hipLaunchKernelGGL(wbc_stats_reduce_kernel, dim3(1), dim3(64), 0, h->stream, h->d_stats, h->d_stats + STAT_SLOTS);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(&s, h->d_stats + STAT_SLOTS, sizeof s, hipMemcpyDeviceToHost));
   out->ticks = s.ticks; out->status_nonzero = s.status_nonzero; out->iters_sum = s.iters_sum;
   out->tau_abs_sum = s.tau_abs_sum; out->err_sum = s.err_sum;
   double mx; memcpy(&mx, &s.tau_abs_max_bits, 8);
@@ -776,7 +838,7 @@ int wbc_stats_get(wbc_handle h, wbc_stats* out) {
 int wbc_stats_reset(wbc_handle h) {
   if (!h) return misuse("wbc_stats_reset: null handle");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipMemsetAsync(h->d_stats, 0, sizeof(StatsDev), h->stream));
+  HIP_TRY(hipMemsetAsync(h->d_stats, 0, sizeof(StatsDev) * (STAT_SLOTS + 1), h->stream));
   return 0;
 }
 
@@ -839,12 +901,18 @@ int wbc_set_variant(wbc_handle h, int variant) {
   return 0;
 }
 
+int wbc_variant_for(wbc_handle h, int n) {
+  if (!h || n < 0) return misuse("wbc_variant_for: bad argument");
+  return pick_variant(h, n);
+}
+
 int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads) {
   if (!h) return misuse("wbc_kernel_info: null handle");
   hipFuncAttributes a;
-  const bool quad = (h->variant == 2) || (h->variant == 0 && !h->lane_only);
+  const int var = h->last_variant ? h->last_variant : pick_variant(h, h->max_batch);
+  const bool quad = (var == 2);
   const void* fn;
-  if (h->variant == 3) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID>
+  if (var == 3) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID>
                : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_kernel<wbc::KIND_MPTC> : (const void*)wbc_hex_kernel<wbc::KIND_PC>;
   else if (quad) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_quad_kernel<wbc::KIND_ID>
                : h->kind == WBC_KIND_MPTC ? (const void*)wbc_quad_kernel<wbc::KIND_MPTC> : (const void*)wbc_quad_kernel<wbc::KIND_PC>;

@@ -96,6 +96,35 @@ def test_quad_all_contact_masks_on_host():
         assert np.allclose(met, met_o, rtol=1e-7, atol=1e-8)
 
 
+@pytest.mark.parametrize("cfg,kind,n", [(2, "id", 24), (3, "mptc", 24), (4, "mptc", 8), (5, "mptc", 8), (3, "pc", 24), (3, "id", 12)])
+def test_hex_kernel_math_emulated_on_host(cfg, kind, n):
+    """wbc_hex.hpp (16 lanes = one DPP row per robot) with the row emulated by 16 lock-step fibres."""
+    b = workloads.make_batch(cfg, n=n)
+    t = orc.load_model_json(b["model"])
+    m = orc.model(b["model"]); p = orc.params(kind)
+    tau_o, met_o, st_o = orc.step_batch(kind, m, p, b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
+    tau, met, st, it, vd = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"],
+                                  hexv=True, want_vdot=True)
+    tq, mq, sq, iq, vdq = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"],
+                                 quad=True, want_vdot=True)
+    assert (st == 0).all()
+    assert rel_err(tau, tau_o).max() < 1e-5
+    assert np.allclose(met, met_o, rtol=1e-7, atol=1e-8)
+    assert np.allclose(vd, vdq, rtol=1e-5, atol=1e-6)          # generalized accelerations agree with the quad mapping
+
+
+def test_hex_all_contact_masks_on_host():
+    b = workloads.make_batch(3, n=16)
+    t = orc.load_model_json("mini_cheetah"); m = orc.model("mini_cheetah")
+    mk = np.arange(16, dtype=np.uint8)
+    for kind in ("id", "mptc", "pc"):
+        tau_o, met_o, st_o = orc.step_batch(kind, m, orc.params(kind), b["q"], b["v"], b["targets"], mk)
+        tau, met, st, it = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], mk, hexv=True)
+        assert (st == 0).all()
+        assert rel_err(tau, tau_o).max() < 1e-5
+        assert np.allclose(met, met_o, rtol=1e-7, atol=1e-8)
+
+
 def test_pc_enforces_passivity_where_mptc_does_not():
     """pc_controller.py: Vdot <= 0 is a hard row; MPTC only logs Vdot."""
     b = workloads.make_batch(3, n=128)

@@ -330,6 +330,7 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
   g_hex = &ctx;
   const size_t STK = 1 << 20;
   static std::vector<char> stacks(16 * STK);
+  static wbc::ParkHost pk[16];
   static wbc::QuadShared sh[16];  // replicated per lane on the host (shared LDS with replicated writes on the device)
   struct Args { int kind, i, stride; const double *q, *v, *tg, *mu, *ms; const unsigned char* mask; double *tau, *met; int *status, *iters; };
   static Args A;
@@ -350,9 +351,9 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
     };
     int it = 0, st;
     const double mui = a.mu ? a.mu[i] : P.mu, msi = a.ms ? a.ms[i] : 1.0;
-    if (a.kind == wbc::KIND_ID) st = wbc::hex_tick<HexHost, wbc::KIND_ID>(m, P, qo, in, a.mask[i], mui, msi, sh[h], ot, om, &it);
-    else if (a.kind == wbc::KIND_PC) st = wbc::hex_tick<HexHost, wbc::KIND_PC>(m, P, qo, in, a.mask[i], mui, msi, sh[h], ot, om, &it);
-    else st = wbc::hex_tick<HexHost, wbc::KIND_MPTC>(m, P, qo, in, a.mask[i], mui, msi, sh[h], ot, om, &it);
+    if (a.kind == wbc::KIND_ID) st = wbc::hex_tick<HexHost, wbc::KIND_ID>(m, P, qo, in, a.mask[i], mui, msi, sh[h], pk[h], ot, om, &it);
+    else if (a.kind == wbc::KIND_PC) st = wbc::hex_tick<HexHost, wbc::KIND_PC>(m, P, qo, in, a.mask[i], mui, msi, sh[h], pk[h], ot, om, &it);
+    else st = wbc::hex_tick<HexHost, wbc::KIND_MPTC>(m, P, qo, in, a.mask[i], mui, msi, sh[h], pk[h], ot, om, &it);
     if (h == 0) { if (a.status) a.status[i] = st; if (a.iters) a.iters[i] = it; }
   };
   for (int i = 0; i < n; i++) {
