@@ -44,11 +44,10 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
     }
     const double s2 = qo.bcast16(t, piv);
     const double rkk = qo.bcast16(Rcol[k], piv);
-    if (!(s2 > 0.0)) continue;
     const double nrm = sqrt(rkk * rkk + s2);
     const double alpha = (rkk > 0.0) ? -nrm : nrm;
     const double v0 = rkk - alpha;
-    const double beta = 1.0 / (nrm * (nrm + fabs(rkk)));  // = 2 / (s2 + v0^2)
+    const double beta = (s2 > 0.0) ? 1.0 / (nrm * (nrm + fabs(rkk))) : 0.0;  // = 2 / (s2 + v0^2); empty column: no-op
     const double s = (v0 * Rcol[k] + t) * beta;
     Rcol[k] -= s * v0;
 #pragma unroll
@@ -56,149 +55,270 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
   }
 }
 
-// Goldfarb-Idnani on the friction rows, 16 lanes per robot.  Jr = own row of J (J J' = H^-1; zero on
-// the sub == 3 lanes), z = own entry.  Friction row p = 4*leg + r is evaluated on lane p itself.
-// Same flat wave-uniform loop as quad_gi (one algorithm step per trip for every unfinished robot).
-template <class Q>
-WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, double inv_s, QuadShared& sh,
-                  int* iters_out, double vrow_own = 0.0, double vc = 0.0, double pc_inv = 0.0) {
-  const int l = h >> 2, sb = h & 3;
-  const bool pc = pc_inv > 0.0;
+// Goldfarb-Idnani on the friction rows, register-resident "constraint-space" form.
+//
+// Friction row h = 4*leg + r lives on lane h.  Besides its row Jr of J (J J' = H^-1) every lane carries
+// Dh = J' n_h (its constraint's image), the running value s_h = n_h' z and, while its row is active,
+// the multiplier u_h, its position in the active list and the reciprocal pivot of its column:
+//   * d = J' n_p is ONE dynamic row broadcast of Dh from lane p (ds_bpermute), not 12 reductions;
+//   * n_p' J2 J2' n_p = |d[q:]|^2, so the primal step length needs no reduction, and |J' n_h| is
+//     invariant under the orthogonal updates of J (computed once);
+//   * s_h advances by t * Dh[q:] . d[q:] (lane-local): picking the most violated row is one argmin;
+//   * J' N_A = [R; 0]: column c of the triangular factor IS Dh[0..c] of the row at position c, so R is never
+//     stored; the lane of the active row at position c (pos_h == c) carries row c of W = R^-1 instead, so the dual
+//     direction r = W d[0:q] is one lane-local dot product (no back-substitution chain).  Appending a
+//     row appends the column [-r/alpha; 1/alpha] to W; dropping one applies the re-triangularising
+//     Givens rotations to the slots of (Jr, Dh, Wr) alike and renumbers the positions;
+//   * the blocking multiplier is a lane-parallel ratio + argmin.
+// Nothing lives in LDS and the loop has no divergent inner branches (profiles/r02/hex_cuts.md).
+// The optional PC row (index 16) is dense: its image/value/multiplier are replicated on all lanes.
+template <class Q, bool PC>
+WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, double inv_s, int* iters_out,
+                  double vrow_own = 0.0, double vc = 0.0, double pc_inv = 0.0) {
+  const int sb = h & 3;
+  const bool pc = PC && pc_inv > 0.0;
+  const double sg = (sb & 1) ? inv_s : -inv_s;   // own row: n_h = sg * e_(leg, sb>>1) + mu_n * e_(leg, 2)
+  double Dh[NZ], sh_, dnh = 0.0;
+#pragma unroll
+  for (int k = 0; k < NZ; k++) {
+    Dh[k] = sg * qo.leg_pairs(Jr[k]) + mu_n * qo.leg_bcast(Jr[k], 2);
+    dnh += Dh[k] * Dh[k];
+  }
+  sh_ = sg * qo.leg_pairs(z) + mu_n * qo.leg_bcast(z, 2);
+  double Dpc[NZ], spc = 0.0, dnpc = 0.0, u_pc = 0.0;
+  int pos_pc = -1;
+  if (PC) {
+    const double npl = -vrow_own * pc_inv;
+#pragma unroll
+    for (int k = 0; k < NZ; k++) { Dpc[k] = qo.sum16(Jr[k] * npl); dnpc += Dpc[k] * Dpc[k]; }
+    spc = -(qo.sum16(vrow_own * z) + vc) * pc_inv;
+  }
+  double u_h = 0.0, Wr[NZ], Wpc[NZ];
+  int pos_h = -1;
+#pragma unroll
+  for (int k = 0; k < NZ; k++) { Wr[k] = 0.0; Wpc[k] = 0.0; }
   int q = 0, iters = 0, status = ST_OK;
   unsigned active = 0u;
   const int maxit = 200;
   bool done = false, need_pick = true;
   int p = -1;
-  double sp = 0.0, npl = 0.0;
+  double sp = 0.0, up = 0.0, dnp = 1.0;
+  const double INF = __builtin_huge_val();
   for (int trip = 0; trip < maxit; trip++) {
     if (!done && need_pick) {
+      // most violated inactive row (argmin of the tracked values) and, independently, the tolerance
       const double zinf = qo.max16(fabs(z));
-      const double tol = 1e-13 * (1.0 + zinf);
-      sp = -tol;
+      sp = INF;
       p = -1;
-      const double z0 = qo.leg_bcast(z, 0), z1 = qo.leg_bcast(z, 1), z2 = qo.leg_bcast(z, 2);
-      if (ct) {
-        const bool act = (active >> h) & 1u;
-        const double zc = (sb >> 1) ? z1 : z0;
-        const double sv = ((sb & 1) ? inv_s : -inv_s) * zc + mu_n * z2;
-        if (!act && sv < sp) { sp = sv; p = h; }
-      }
+      if (ct && !((active >> h) & 1u)) { sp = sh_; p = h; }
       qo.argmin16(sp, p);
-      if (pc && !((active >> 16) & 1u)) {
-        const double sv = -(qo.sum16(vrow_own * z) + vc) * pc_inv;
-        if (sv < sp) { sp = sv; p = 16; }
-      }
+      if (pc && !((active >> 16) & 1u) && spc < sp) { sp = spc; p = 16; }
+      if (!(sp < -1e-13 * (1.0 + zinf))) p = -1;
       if (p < 0) {
         done = true;
       } else {
-        if (p == 16) {
-          npl = -vrow_own * pc_inv;
-        } else {
-          const int owner = p >> 2, rr = p & 3;
-          const double sg = (rr & 1) ? inv_s : -inv_s;
-          const double mine = (sb == 0) ? ((rr >> 1) ? 0.0 : sg) : ((sb == 1) ? ((rr >> 1) ? sg : 0.0) : ((sb == 2) ? mu_n : 0.0));
-          npl = (l == owner) ? mine : 0.0;
-        }
-        sh.u[q] = 0.0;
+        up = 0.0;
+        dnp = qo.bcast16d(dnh, p & 15);
+        if (PC) dnp = (p == 16) ? dnpc : dnp;
         need_pick = false;
       }
     }
     if (qo.wave_all(done)) break;
     if (done) continue;
     iters++;
-    double d[NZ], dn = 0.0, d2n = 0.0;
+    double d[NZ], dm[NZ], d2n = 0.0;
 #pragma unroll
     for (int k = 0; k < NZ; k++) {
-      d[k] = qo.sum16(Jr[k] * npl);
-      dn += d[k] * d[k];
-      if (k >= q) d2n += d[k] * d[k];
+      d[k] = qo.bcast16d(Dh[k], p & 15);
+      if (PC) d[k] = (p == 16) ? Dpc[k] : d[k];
+      dm[k] = (k >= q) ? d[k] : 0.0;
+      d2n += dm[k] * dm[k];
     }
-    double zd = 0.0;
+    double zd = 0.0, sd = 0.0, sdpc = 0.0;
 #pragma unroll
-    for (int k = 0; k < NZ; k++) zd += Jr[k] * ((k >= q) ? d[k] : 0.0);
-    double r[NZ];
-    int ldrop;
-    double t1n, t1d;
-    const int qmax = qo.wave_max_int(q);
-    if (qmax <= 3) gi_dual<3>(sh, q, d, r, ldrop, t1n, t1d);
-    else if (qmax <= 6) gi_dual<6>(sh, q, d, r, ldrop, t1n, t1d);
-    else gi_dual<NZ>(sh, q, d, r, ldrop, t1n, t1d);
-    const bool have_t1 = ldrop >= 0;
-    const double t1 = have_t1 ? t1n / t1d : 0.0;
-    const bool dependent = !(d2n > 1e-22 * dn) || q == NZ;
-    const double znp = qo.sum16(zd * npl);
-    const double t2 = dependent ? 0.0 : -sp / znp;
+    for (int k = 0; k < NZ; k++) {
+      zd += Jr[k] * dm[k];
+      sd += Dh[k] * dm[k];
+      if (PC) sdpc += Dpc[k] * dm[k];
+    }
+    // dual step direction r = R^-1 d[0:q]: every active row's lane holds its row of W = R^-1
+    double r_h = 0.0, r_pc = 0.0;
+#pragma unroll
+    for (int k = 0; k < NZ; k++) {
+      const double d1 = d[k] - dm[k];
+      r_h += Wr[k] * d1;
+      if (PC) r_pc += Wpc[k] * d1;
+    }
+    r_h = (pos_h >= 0) ? r_h : 0.0;
+    if (PC) r_pc = (pos_pc >= 0) ? r_pc : 0.0;
+    // blocking multiplier: min over active rows with r > 0 of u / r
+    double t1 = (pos_h >= 0 && r_h > 0.0) ? u_h / r_h : INF;
+    int hd = (t1 < INF) ? h : -1;
+    qo.argmin16(t1, hd);
+    if (PC) {
+      const double c = (pos_pc >= 0 && r_pc > 0.0) ? u_pc / r_pc : INF;
+      if (c < t1) { t1 = c; hd = 16; }
+    }
+    const bool have_t1 = hd >= 0;
+    const bool dependent = !(d2n > 1e-22 * dnp) || q == NZ;
+    const double t2 = -sp / d2n;   // n_p' J2 J2' n_p = |d[q:]|^2
     if (dependent && !have_t1) { status = ST_SINGULAR; done = true; continue; }
     const bool full = !dependent && (!have_t1 || !(t1 < t2));
     const double t = full ? t2 : t1;
-#pragma unroll
-    for (int k = 0; k < NZ; k++)
-      if (k < q) sh.u[k] -= t * r[k];
-    sh.u[q] += t;
-    if (!dependent) z += t * zd;
+    u_h -= t * r_h;
+    if (PC) u_pc -= t * r_pc;
+    up += t;
+    {
+      const double tz = dependent ? 0.0 : t;
+      z += tz * zd;
+      sh_ += tz * sd;
+      if (PC) spc += tz * sdpc;
+      sp += tz * d2n;
+    }
     if (full) {
+      // one Householder reflection H on d[q:] (H d2 = alpha e_q);  J2 <- J2 H on the own row, images alike
       double dq = 0.0;
 #pragma unroll
       for (int k = 0; k < NZ; k++) dq = (k == q) ? d[k] : dq;
       const double nrm = sqrt(d2n);
       const double alpha = (dq > 0.0) ? -nrm : nrm;
       const double vq = dq - alpha;
-      const double vv = d2n - dq * dq + vq * vq;
-      if (vv > 0.0) {
-        const double beta = 2.0 / vv;
-        double w = 0.0;
-        double hv[NZ];
+      const double ia = 1.0 / alpha;
+      const double beta = fabs(ia) / (nrm + fabs(dq));   // 2 / (v'v) = 1 / (nrm (nrm + |dq|))
+      double w = 0.0, wd = 0.0, wp = 0.0;
+      double hv[NZ];
 #pragma unroll
-        for (int k = 0; k < NZ; k++) {
-          hv[k] = (k < q) ? 0.0 : ((k == q) ? vq : d[k]);
-          w += Jr[k] * hv[k];
-        }
-        w *= beta;
-#pragma unroll
-        for (int k = 0; k < NZ; k++) Jr[k] -= w * hv[k];
+      for (int k = 0; k < NZ; k++) {
+        hv[k] = (k == q) ? vq : dm[k];
+        w += Jr[k] * hv[k];
+        wd += Dh[k] * hv[k];
+        if (PC) wp += Dpc[k] * hv[k];
       }
+      w *= beta; wd *= beta; wp *= beta;
 #pragma unroll
-      for (int k = 0; k < NZ; k++)
-        if (k < q) sh.Rq[k][q] = d[k];
-      sh.Rq[q][q] = 1.0 / alpha;
-      sh.A[q] = p;
+      for (int k = 0; k < NZ; k++) {
+        Jr[k] -= w * hv[k];
+        Dh[k] -= wd * hv[k];
+        if (PC) Dpc[k] -= wp * hv[k];
+      }
+      // W' = [W, -r/alpha; 0, 1/alpha]  (rows of inactive lanes are zero, r_h = 0 there)
+      const bool mine = (h == p);
+      {
+        const double wq = mine ? ia : -r_h * ia;
+#pragma unroll
+        for (int k = 0; k < NZ; k++) Wr[k] = (k == q) ? wq : Wr[k];
+      }
+      u_h = mine ? up : u_h;
+      pos_h = mine ? q : pos_h;
+      if (PC) {
+        const bool pm = (p == 16);
+        const double wq = pm ? ia : -r_pc * ia;
+#pragma unroll
+        for (int k = 0; k < NZ; k++) Wpc[k] = (k == q) ? wq : Wpc[k];
+        u_pc = pm ? up : u_pc; pos_pc = pm ? q : pos_pc;
+      }
       active |= (1u << p);
       q++;
       need_pick = true;
       continue;
     }
-    // partial / pure dual step: drop active constraint ldrop (see quad_gi for the storage convention)
-    active &= ~(1u << sh.A[ldrop]);
-    for (int j = ldrop; j < q - 1; j++) {
-      sh.A[j] = sh.A[j + 1];
-      sh.u[j] = sh.u[j + 1];
-      for (int k = 0; k <= j + 1; k++) sh.Rq[k][j] = sh.Rq[k][j + 1];
-    }
-    sh.u[q - 1] = sh.u[q];
-    q--;
-    sh.u[q + 1] = 0.0;
-    for (int j = ldrop; j < q; j++) {
-      const double a = sh.Rq[j][j], bb = 1.0 / sh.Rq[j + 1][j];
-      const double hh = sqrt(a * a + bb * bb), c = a / hh, sn = bb / hh;
-      sh.Rq[j][j] = 1.0 / hh;
-      for (int k = j + 1; k < q; k++) {
-        const double x = sh.Rq[j][k], y = sh.Rq[j + 1][k];
-        sh.Rq[j][k] = c * x + sn * y;
-        sh.Rq[j + 1][k] = c * y - sn * x;
-      }
+    // partial / pure dual step: drop the active row hd (list position ld)
+    {
+      int ld = qo.bcast16d_i(pos_h, hd & 15);
+      if (PC) ld = (hd == 16) ? pos_pc : ld;
+      active &= ~(1u << hd);
+      {
+        const bool mine = (h == hd);
+        u_h = mine ? 0.0 : u_h;
+        pos_h = mine ? -1 : ((pos_h > ld) ? pos_h - 1 : pos_h);
 #pragma unroll
-      for (int jj = 0; jj < NZ - 1; jj++) {
-        if (jj != j) continue;
-        const double x = Jr[jj], y = Jr[jj + 1];
-        Jr[jj] = c * x + sn * y;
-        Jr[jj + 1] = c * y - sn * x;
+        for (int k = 0; k < NZ; k++) Wr[k] = mine ? 0.0 : Wr[k];
+      }
+      if (PC) {
+        const bool pm = (hd == 16);
+        u_pc = pm ? 0.0 : u_pc;
+        pos_pc = pm ? -1 : ((pos_pc > ld) ? pos_pc - 1 : pos_pc);
+#pragma unroll
+        for (int k = 0; k < NZ; k++) Wpc[k] = pm ? 0.0 : Wpc[k];
+      }
+      q--;
+      // columns ld..q-1 now carry one sub-diagonal entry each: rotate rows (j, j+1), j = ld..q-1
+#pragma unroll
+      for (int j = 0; j < NZ - 1; j++) {
+        if (j >= ld && j < q) {
+          // (a, b) = entries (j, j+1) of the column now at position j: the image of the row whose position is j
+          const bool here = (pos_h == j);
+          double a = qo.sum16(here ? Dh[j] : 0.0), b = qo.sum16(here ? Dh[j + 1] : 0.0);
+          if (PC) { a = (pos_pc == j) ? Dpc[j] : a; b = (pos_pc == j) ? Dpc[j + 1] : b; }
+          const double ih = 1.0 / sqrt(a * a + b * b);
+          const double c = a * ih, sn = b * ih;
+          {
+            const double x = Wr[j], y = Wr[j + 1];
+            Wr[j] = c * x + sn * y;
+            Wr[j + 1] = c * y - sn * x;
+          }
+          if (PC) {
+            const double x = Wpc[j], y = Wpc[j + 1];
+            Wpc[j] = c * x + sn * y;
+            Wpc[j + 1] = c * y - sn * x;
+          }
+          {
+            const double x = Jr[j], y = Jr[j + 1];
+            Jr[j] = c * x + sn * y;
+            Jr[j + 1] = c * y - sn * x;
+          }
+          {
+            const double x = Dh[j], y = Dh[j + 1];
+            Dh[j] = c * x + sn * y;
+            Dh[j + 1] = c * y - sn * x;
+          }
+          if (PC) {
+            const double x = Dpc[j], y = Dpc[j + 1];
+            Dpc[j] = c * x + sn * y;
+            Dpc[j + 1] = c * y - sn * x;
+          }
+        }
       }
     }
-    if (!dependent) sp = qo.sum16(npl * z) - ((p == 16) ? vc * pc_inv : 0.0);
   }
   *iters_out = iters;
   if (!done && status == ST_OK) status = ST_ITER;
   return status;
+}
+
+// 6x6 solve without row exchanges for NR right-hand sides held as extra columns.  G_b = M_bb - sum X Jfb is
+// the base's 6x6 composite inertia (symmetric positive definite, dominant) minus the light legs' coupling,
+// so elimination in natural order is stable; a collapsed pivot is reported through the returned
+// min|pivot| / max|pivot| exactly like the pivoted solve6 (the caller turns it into status 2).
+// Row exchanges on register arrays cost ~400 v_cndmask per tick on this kernel.
+template <int NR> WBC_HD double solve6np(double (*Ab)[6 + NR]) {
+  double pmin = 0.0, pmax = 0.0;
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    const double best = fabs(Ab[c][c]);
+    if (c == 0 || best < pmin) pmin = best;
+    if (best > pmax) pmax = best;
+    const double id = 1.0 / Ab[c][c];
+#pragma unroll
+    for (int j = c + 1; j < 6 + NR; j++) Ab[c][j] *= id;   // row c scaled: unit diagonal
+#pragma unroll
+    for (int r = c + 1; r < 6; r++) {
+      const double f = Ab[r][c];
+#pragma unroll
+      for (int j = c + 1; j < 6 + NR; j++) Ab[r][j] -= f * Ab[c][j];
+    }
+  }
+#pragma unroll
+  for (int c = 5; c >= 0; c--) {
+#pragma unroll
+    for (int n = 0; n < NR; n++) {
+      double sacc = Ab[c][6 + n];
+#pragma unroll
+      for (int j = c + 1; j < 6; j++) sacc -= Ab[c][j] * Ab[j][6 + n];
+      Ab[c][6 + n] = sacc;
+    }
+  }
+  return pmin / pmax;
 }
 
 // Robot-level cold storage ("park"): replicated values that are produced early and consumed late
@@ -212,6 +332,21 @@ struct ParkHost {
   double get(int i) const { return d[i]; }
 };
 
+// Diagnostic builds only (-DWBC_HCUT=k): return after phase k with the live values folded into the
+// outputs (see WBC_CUT_AT in wbc_quad.hpp); timed as whole kernels -> profiles/r02/hex_cuts.md.
+#ifdef WBC_HCUT
+#define WBC_HCUT_AT(k, expr)                                                  \
+  if (WBC_HCUT == (k)) {                                                      \
+    double sink_ = (expr);                                                    \
+    if (colv) out_tau(m.act_inv[3 * l + sb], sink_);                          \
+    out_met(0, sink_); out_met(1, sink_); out_met(2, 0.0); out_met(3, 0.0);   \
+    *iters_out = 0;                                                           \
+    return ST_OK;                                                             \
+  }
+#else
+#define WBC_HCUT_AT(k, expr)
+#endif
+
 // per-lane pick of element `sb` (0..2) of a replicated triple
 WBC_HD double pick3(int sb, double a, double b, double c) { return (sb == 0) ? a : ((sb == 1) ? b : c); }
 
@@ -219,7 +354,7 @@ WBC_HD double pick3(int sb, double a, double b, double c) { return (sb == 0) ? a
 // out_tau(row, x): lane (leg, j<3) writes the torque of joint 3*leg+j;  out_met: see the kernel.
 template <class Q, int KIND, class Park, class In, class OutTau, class OutMet>
 WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned mask, double mu, double mass_scale,
-                    QuadShared& sh, Park& pk, OutTau out_tau, OutMet out_met, int* iters_out) {
+                    Park& pk, OutTau out_tau, OutMet out_met, int* iters_out) {
   const int h = qo.lane();
   const int l = h >> 2, sb = h & 3;
   const bool ct = (mask >> l) & 1u;
@@ -288,6 +423,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       }
     }
   }
+  WBC_HCUT_AT(1, xt_b[0] + xt_b[4] + xdt_b[1] + xdt_b[5] + xdd_b[2] + ades[1] + bI[3] + bmc[1] + R0[5] + rpyd[0] + E[3])
   // ---------------- own leg (replicated on its four sub-lanes unless noted)
   double rf[3], Jdv[3], pd[3], rd[3], hl[3];
   double X[18], Y[18], Pm[9], Jl[9], Ji[9], Mll6[6];
@@ -407,15 +543,18 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
                         ct ? (-P.Kd_contact * pd[2] - Jdv[2]) : 0.0};
   // own row of t0 (without the Y ab0 part) and of the torque map's diagonal block D_l
   // (-Jl' for a contact leg, Pm for a swing leg); meaningful on the column lanes (sub < 3)
-  double t0_own, Yrow[6], Drow[3];
+  double t0_own, Yrow[6], Drow[3], Dcol[3];   // Dcol[i] = D_l[i][sub]: own column of the diagonal block
   {
     double t0l[3];
     for (int i = 0; i < 3; i++) t0l[i] = hl[i] + (Pm[3 * i] * bc[0] + Pm[3 * i + 1] * bc[1] + Pm[3 * i + 2] * bc[2]);
     t0_own = pick3(sb, t0l[0], t0l[1], t0l[2]);
     for (int k = 0; k < 6; k++) Yrow[k] = pick3(sb, Y[k], Y[6 + k], Y[12 + k]);
-    for (int j = 0; j < 3; j++)
+    for (int j = 0; j < 3; j++) {
       Drow[j] = ct ? -pick3(sb, Jl[3 * j], Jl[3 * j + 1], Jl[3 * j + 2]) : pick3(sb, Pm[j], Pm[3 + j], Pm[6 + j]);
+      Dcol[j] = ct ? -pick3(sb, Jl[j], Jl[3 + j], Jl[6 + j]) : pick3(sb, Pm[3 * j], Pm[3 * j + 1], Pm[3 * j + 2]);
+    }
   }
+  WBC_HCUT_AT(2, X[0] + X[7] + X[17] + Y[3] + Y[16] + hbN[0] + hbN[5] + lm + lh[1] + lI[3] + Cb_leg[2] + Cl[1] + xi[0] + t0_own + Yrow[2] + Drow[1] + Ji[4] + Mll6[2] + jdxi[0] + xt_s[0] + xdt_s[1] + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1])
   // ---------------- base: bias wrench, composite inertia -> Gs = G_b, kv
   double Gs[6][6], kv[6];
   {
@@ -471,13 +610,14 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       const double xc = pick3(sb, X[3 * i], X[3 * i + 1], X[3 * i + 2]);
       Ab[i][6] = colv ? (ct ? wc[i] : -xc) : -kv[i];
     }
-    const double rc = solve6<1>(Ab);
+    const double rc = solve6np<1>(Ab);
     if (!(rc > 1e-12)) status = ST_SINGULAR;
     for (int i = 0; i < 6; i++) {
       bcol[i] = Ab[i][6];
       ab0[i] = qo.leg_bcast(bcol[i], 3);
     }
   }
+  WBC_HCUT_AT(3, bcol[0] + bcol[5] + ab0[2] + Cb_leg[2] + Cl[1] + xi[0] + t0_own + Yrow[2] + Drow[1] + Y[4] + Ji[4] + Mll6[2] + jdxi[0] + xt_s[0] + xdt_s[1] + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1] + kv[0])
   // ---------------- level-1 rows
   const double eps = sqrt(P.eps2);
   const double sw_b = sqrt(P.w_body), sw_f = sqrt(P.w_foot);
@@ -609,9 +749,9 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     // 12 swing rows sqrt(w_foot) [Lambda_sb a_b + Lambda_ss z_leg + c1]; zero for contact legs.
     // Row (lp, i) is owned by lane (lp, i): its Lambda_sb row (6), c1 and Lambda_ss row (3).
     {
-      double Msb[6], Mss[3];
+      double Msb[6], Msc[3];   // Msc[i] = Lambda_ss[i][sub]: own column of the leg's swing block
       for (int k = 0; k < 6; k++) Msb[k] = ct ? 0.0 : pick3(sb, Mt_bl[3 * k], Mt_bl[3 * k + 1], Mt_bl[3 * k + 2]);
-      for (int j = 0; j < 3; j++) Mss[j] = ct ? 0.0 : pick3(sb, Mt_ll[j], Mt_ll[3 + j], Mt_ll[6 + j]);
+      for (int i = 0; i < 3; i++) Msc[i] = ct ? 0.0 : pick3(sb, Mt_ll[3 * i], Mt_ll[3 * i + 1], Mt_ll[3 * i + 2]);
       const double c1o = ct ? 0.0 : pick3(sb, c1_s[0], c1_s[1], c1_s[2]);
 #pragma unroll
       for (int r = 0; r < NZ; r++) {
@@ -620,15 +760,14 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
 #pragma unroll
         for (int k = 0; k < 6; k++) dotv += qo.bcast16(Msb[k], src) * bcol[k];
         const double c1r = qo.bcast16(c1o, src);
-        // Lambda_ss entry (row r, own column): only within the own leg
-        const double m0 = qo.bcast16(Mss[0], src), m1 = qo.bcast16(Mss[1], src), m2 = qo.bcast16(Mss[2], src);
-        const double dg = (r / 3 == l) ? pick3(sb, m0, m1, m2) : 0.0;
+        const double dg = (r / 3 == l) ? Msc[r % 3] : 0.0;   // Lambda_ss entry (row r, own column): own leg only
         Acol[6 + r] = colv ? sw_f * (dotv + dg) : -sw_f * (c1r + dotv);
       }
     }
     init_rcol();
     hex_qr_append<Q, 18>(qo, Rcol, Acol);
   }
+  WBC_HCUT_AT(4, Rcol[0] + Rcol[5] + Rcol[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- level-2 rows eps (T z + t0):  T[(l',i)][(l,j)] = Y_l'[i] . B_l[:,j] + delta D_l[i][j]
   {
     double Acol[NZ];
@@ -639,12 +778,12 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
 #pragma unroll
       for (int k = 0; k < 6; k++) dotv += qo.bcast16(Yrow[k], src) * bcol[k];
       const double t0r = qo.bcast16(t0_own, src);
-      const double d0 = qo.bcast16(Drow[0], src), d1 = qo.bcast16(Drow[1], src), d2 = qo.bcast16(Drow[2], src);
-      const double dg = (r / 3 == l) ? pick3(sb, d0, d1, d2) : 0.0;
+      const double dg = (r / 3 == l) ? Dcol[r % 3] : 0.0;
       Acol[r] = colv ? eps * (dotv + dg) : -eps * (t0r + dotv);
     }
     hex_qr_append<Q, 12>(qo, Rcol, Acol);
   }
+  WBC_HCUT_AT(5, Rcol[0] + Rcol[5] + Rcol[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- own row of J = R^-1 and unconstrained minimiser
   double z, Jr[NZ];
   {
@@ -683,6 +822,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     }
     z = zacc;
   }
+  WBC_HCUT_AT(6, z + Jr[0] + Jr[5] + Jr[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- friction rows
   int iters = 0;
   {
@@ -691,13 +831,14 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     if (KIND == KIND_PC) {
       const double vr = colv ? vrow_own : 0.0;
       const double n2 = qo.sum16(vr * vr);
-      st = hex_gi(qo, h, ct, Jr, z, mu / s, 1.0 / s, sh, &iters, vr, vconst + met_Vdot, (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0);
+      st = hex_gi<Q, true>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, vr, vconst + met_Vdot, (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0);
     } else {
-      st = hex_gi(qo, h, ct, Jr, z, mu / s, 1.0 / s, sh, &iters);
+      st = hex_gi<Q, false>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters);
     }
     if (st != ST_OK) status = st;
   }
   *iters_out = iters;
+  WBC_HCUT_AT(7, z + (double)iters + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- outputs: a_b = ab0 + sum B z ;  tau_(l,j) = Y_l[j] a_b + D_l[j] z_l + t0_l[j]
   const double z0 = qo.leg_bcast(z, 0), z1 = qo.leg_bcast(z, 1), z2 = qo.leg_bcast(z, 2);
   {

@@ -380,6 +380,10 @@ struct HexDev {
       default: return dpp<0xFF>(x);
     }
   }
+  __device__ __forceinline__ double leg_pairs(double x) const { return dpp<0x50>(x); }  // quad_perm [0,0,1,1]
+  // dynamic (robot-uniform) source lane within the row: ds_bpermute (LDS crossbar, no LDS memory)
+  __device__ __forceinline__ double bcast16d(double x, int src) const { return __shfl(x, (threadIdx.x & 48) | src, 64); }
+  __device__ __forceinline__ int bcast16d_i(int x, int src) const { return __shfl(x, (threadIdx.x & 48) | src, 64); }
   __device__ __forceinline__ double leg_sum(double x) const {
     x += dpp<0xB1>(x);
     x += dpp<0x4E>(x);
@@ -446,7 +450,6 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
                int32_t* __restrict__ status, StatsDev* __restrict__ stats, double* __restrict__ vdot) {
   __shared__ double mbuf[MODEL_PAD_WORDS];
   __shared__ double inbuf[NIN * HROBOTS];
-  __shared__ wbc::QuadShared shq[HROBOTS];
   __shared__ double parkbuf[HROBOTS * wbc::PK_N];
   const int slot = threadIdx.x >> 4;
   const int i = blockIdx.x * HROBOTS + slot;
@@ -507,27 +510,24 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   for (int k = 0; k < WBC_FORCE_SCRATCH; k++) junk[k] = inbuf[k];
 #endif
   ParkLds park(parkbuf + slot * wbc::PK_N);
-  const int st = wbc::hex_tick<HexDev, KIND>(m, P, qo, in, mk, mui, msi, shq[slot], park, ot, om, &iters);
+  const int st = wbc::hex_tick<HexDev, KIND>(m, P, qo, in, mk, mui, msi, park, ot, om, &iters);
 #ifdef WBC_FORCE_SCRATCH
   if (junk[threadIdx.x % WBC_FORCE_SCRATCH] == 1.2345e300) iters++;
 #endif
   if (live && lead && status) status[ii] = st;
   if (stats) {
-    stats += blockIdx.x & (STAT_SLOTS - 1);
-    const double lv = (live && lead) ? 1.0 : 0.0, la = live ? 1.0 : 0.0;
-    double a = wave_sum(lv), b = wave_sum((live && lead && st != 0) ? 1.0 : 0.0), c = wave_sum(lv * iters);
-    double d = wave_sum(la * tsum), e = wave_max(la * tmax), f = wave_sum(lv * errv);
-    unsigned long long bal[16];
-    for (int k = 0; k < 16; k++) bal[k] = __ballot(live && lead && mk == (unsigned)k);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&stats->ticks, a);
-      if (b != 0.0) atomicAdd(&stats->status_nonzero, b);
-      atomicAdd(&stats->iters_sum, c);
-      atomicAdd(&stats->tau_abs_sum, d);
-      atomicMax(&stats->tau_abs_max_bits, (unsigned long long)__double_as_longlong(e));
-      atomicAdd(&stats->err_sum, f);
-      for (int k = 0; k < 16; k++)
-        if (bal[k]) atomicAdd(&stats->mask_count[k], (double)__popcll(bal[k]));
+    // per-robot reductions on the DPP row, then fire-and-forget atomics from the robot's lead lane into
+    // the block's slot (no wave-wide shuffles, no waits at the tail of the kernel)
+    const double ts = qo.sum16(tsum), tm = qo.max16(tmax);
+    if (live && lead) {
+      stats += blockIdx.x & (STAT_SLOTS - 1);
+      atomicAdd(&stats->ticks, 1.0);
+      if (st != 0) atomicAdd(&stats->status_nonzero, 1.0);
+      atomicAdd(&stats->iters_sum, (double)iters);
+      atomicAdd(&stats->tau_abs_sum, ts);
+      atomicMax(&stats->tau_abs_max_bits, (unsigned long long)__double_as_longlong(tm));
+      atomicAdd(&stats->err_sum, errv);
+      atomicAdd(&stats->mask_count[mk], 1.0);
     }
   }
 }

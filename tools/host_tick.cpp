@@ -270,6 +270,13 @@ struct HexHost {
   }
   double bcast16(double x, int src) { return xchg(x, src); }
   double leg_bcast(double x, int s0) { return xchg(x, (h & ~3) | s0); }
+  double leg_pairs(double x) { return xchg(x, (h & ~3) | ((h & 3) >> 1)); }   // quad_perm [0,0,1,1]
+  double bcast16d(double x, int src) { return xchg(x, src); }                  // dynamic (robot-uniform) source lane
+  int bcast16d_i(int x, int src) {
+    g_hex->islot[h] = x; hex_barrier(h);
+    const int r = g_hex->islot[src]; hex_barrier(h);
+    return r;
+  }
   static double quad_of(const double* s, int b) { return (s[b] + s[b ^ 1]) + (s[b ^ 2] + s[b ^ 3]); }
   double leg_sum(double x) {
     g_hex->slot[h] = x; hex_barrier(h);
@@ -331,7 +338,6 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
   const size_t STK = 1 << 20;
   static std::vector<char> stacks(16 * STK);
   static wbc::ParkHost pk[16];
-  static wbc::QuadShared sh[16];  // replicated per lane on the host (shared LDS with replicated writes on the device)
   struct Args { int kind, i, stride; const double *q, *v, *tg, *mu, *ms; const unsigned char* mask; double *tau, *met; int *status, *iters; };
   static Args A;
   A = Args{kind, 0, stride, q, v, tg, mu, mass_scale, mask, tau, met, status, iters};
@@ -351,14 +357,13 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
     };
     int it = 0, st;
     const double mui = a.mu ? a.mu[i] : P.mu, msi = a.ms ? a.ms[i] : 1.0;
-    if (a.kind == wbc::KIND_ID) st = wbc::hex_tick<HexHost, wbc::KIND_ID>(m, P, qo, in, a.mask[i], mui, msi, sh[h], pk[h], ot, om, &it);
-    else if (a.kind == wbc::KIND_PC) st = wbc::hex_tick<HexHost, wbc::KIND_PC>(m, P, qo, in, a.mask[i], mui, msi, sh[h], pk[h], ot, om, &it);
-    else st = wbc::hex_tick<HexHost, wbc::KIND_MPTC>(m, P, qo, in, a.mask[i], mui, msi, sh[h], pk[h], ot, om, &it);
+    if (a.kind == wbc::KIND_ID) st = wbc::hex_tick<HexHost, wbc::KIND_ID>(m, P, qo, in, a.mask[i], mui, msi, pk[h], ot, om, &it);
+    else if (a.kind == wbc::KIND_PC) st = wbc::hex_tick<HexHost, wbc::KIND_PC>(m, P, qo, in, a.mask[i], mui, msi, pk[h], ot, om, &it);
+    else st = wbc::hex_tick<HexHost, wbc::KIND_MPTC>(m, P, qo, in, a.mask[i], mui, msi, pk[h], ot, om, &it);
     if (h == 0) { if (a.status) a.status[i] = st; if (a.iters) a.iters[i] = it; }
   };
   for (int i = 0; i < n; i++) {
     A.i = i;
-    memset(sh, 0, sizeof sh);
     ctx.count = 0;
     for (int h = 0; h < 16; h++) {
       ctx.finished[h] = false;
