@@ -149,7 +149,7 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
 
 /* Kernel variant: 0 = auto (default), 1 = lane-per-robot, 2 = quad-per-robot (4 lanes = 4 legs),
  * 3 = 16 lanes (one DPP row) per robot.  All compute the same tick.  Auto picks by batch size:
- * 16-lane while n/4 wavefronts fit one (ID) / two (MPTC, PC) per SIMD, quad beyond; lane-per-robot
+ * 16-lane while n/4 wavefronts fit two (ID) / four (MPTC, PC) per SIMD, quad beyond; lane-per-robot
  * when the optional torque box is enabled or the kind is WBC_KIND_CLF (13 reduced variables). */
 int wbc_set_variant(wbc_handle h, int variant);
 /* The variant (1, 2 or 3) a wbc_step of n instances would run. */

@@ -152,16 +152,16 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     r_h = (pos_h >= 0) ? r_h : 0.0;
     if (PC) r_pc = (pos_pc >= 0) ? r_pc : 0.0;
     // blocking multiplier: min over active rows with r > 0 of u / r
-    double t1 = (pos_h >= 0 && r_h > 0.0) ? u_h / r_h : INF;
+    double t1 = (pos_h >= 0 && r_h > 0.0) ? u_h * fast_rcp(r_h) : INF;
     int hd = (t1 < INF) ? h : -1;
     qo.argmin16(t1, hd);
     if (PC) {
-      const double c = (pos_pc >= 0 && r_pc > 0.0) ? u_pc / r_pc : INF;
+      const double c = (pos_pc >= 0 && r_pc > 0.0) ? u_pc * fast_rcp(r_pc) : INF;
       if (c < t1) { t1 = c; hd = 16; }
     }
     const bool have_t1 = hd >= 0;
     const bool dependent = !(d2n > 1e-22 * dnp) || q == NZ;
-    const double t2 = -sp / d2n;   // n_p' J2 J2' n_p = |d[q:]|^2
+    const double t2 = -sp * fast_rcp(d2n);   // n_p' J2 J2' n_p = |d[q:]|^2
     if (dependent && !have_t1) { status = ST_SINGULAR; done = true; continue; }
     const bool full = !dependent && (!have_t1 || !(t1 < t2));
     const double t = full ? t2 : t1;
@@ -180,11 +180,11 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       double dq = 0.0;
 #pragma unroll
       for (int k = 0; k < NZ; k++) dq = (k == q) ? d[k] : dq;
-      const double nrm = sqrt(d2n);
+      const double nrm = fast_sqrt(d2n);
       const double alpha = (dq > 0.0) ? -nrm : nrm;
       const double vq = dq - alpha;
-      const double ia = 1.0 / alpha;
-      const double beta = fabs(ia) / (nrm + fabs(dq));   // 2 / (v'v) = 1 / (nrm (nrm + |dq|))
+      const double ia = fast_rcp(alpha);
+      const double beta = fast_rcp(nrm * (nrm + fabs(dq)));   // 2 / (v'v)
       double w = 0.0, wd = 0.0, wp = 0.0;
       double hv[NZ];
 #pragma unroll
@@ -250,7 +250,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
           const bool here = (pos_h == j);
           double a = qo.sum16(here ? Dh[j] : 0.0), b = qo.sum16(here ? Dh[j + 1] : 0.0);
           if (PC) { a = (pos_pc == j) ? Dpc[j] : a; b = (pos_pc == j) ? Dpc[j + 1] : b; }
-          const double ih = 1.0 / sqrt(a * a + b * b);
+          const double ih = fast_rcp(fast_sqrt(a * a + b * b));
           const double c = a * ih, sn = b * ih;
           {
             const double x = Wr[j], y = Wr[j + 1];
@@ -445,7 +445,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
         wbc_sincos(th, sn[k], cs[k]);
         qd[k] = in(25 + row);
       }
-      leg_fk(m, l, R0, sn, cs, K);
+      leg_fk_vec(m, l, R0, sn, cs, K);
     }
     leg_crba(mass3, K, D, lm, lh, lI);
     for (int i = 0; i < 3; i++) rf[i] = K.rf(i);
@@ -643,6 +643,20 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       Rcol[k] = colv ? ((hex_lane(k) == h) ? dval : 0.0) : rk;
     }
   };
+  // level-2 rows eps (T z + t0):  T[(l',i)][(l,j)] = Y_l'[i] . B_l[:,j] + delta D_l[i][j].  (Folding them into
+  // the level-1 append -- one pass of 12 pivots over 30 rows -- was measured: it spills, profiles/r02.)
+  auto level2_rows = [&](double* A2) {
+#pragma unroll
+    for (int r = 0; r < NZ; r++) {
+      const int src = hex_lane(r);
+      double dotv = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) dotv += qo.bcast16(Yrow[k], src) * bcol[k];
+      const double t0r = qo.bcast16(t0_own, src);
+      const double dg = (r / 3 == l) ? Dcol[r % 3] : 0.0;
+      A2[r] = colv ? eps * (dotv + dg) : -eps * (t0r + dotv);
+    }
+  };
   if (KIND == KIND_ID) {
     double Acol[6];
     for (int i = 0; i < 6; i++) Acol[i] = colv ? sw_b * bcol[i] : sw_b * (ades[i] - bcol[i]);
@@ -768,20 +782,10 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     hex_qr_append<Q, 18>(qo, Rcol, Acol);
   }
   WBC_HCUT_AT(4, Rcol[0] + Rcol[5] + Rcol[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
-  // ---------------- level-2 rows eps (T z + t0):  T[(l',i)][(l,j)] = Y_l'[i] . B_l[:,j] + delta D_l[i][j]
   {
-    double Acol[NZ];
-#pragma unroll
-    for (int r = 0; r < NZ; r++) {
-      const int src = hex_lane(r);
-      double dotv = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; k++) dotv += qo.bcast16(Yrow[k], src) * bcol[k];
-      const double t0r = qo.bcast16(t0_own, src);
-      const double dg = (r / 3 == l) ? Dcol[r % 3] : 0.0;
-      Acol[r] = colv ? eps * (dotv + dg) : -eps * (t0r + dotv);
-    }
-    hex_qr_append<Q, 12>(qo, Rcol, Acol);
+    double A2[NZ];
+    level2_rows(A2);
+    hex_qr_append<Q, NZ>(qo, Rcol, A2);
   }
   WBC_HCUT_AT(5, Rcol[0] + Rcol[5] + Rcol[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- own row of J = R^-1 and unconstrained minimiser

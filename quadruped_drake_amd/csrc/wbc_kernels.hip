@@ -178,7 +178,7 @@ struct QuadDev {
 
 constexpr int QROBOTS = BLOCK / 4;  // robots per 64-lane block
 constexpr int NIN = 19 + 18 + 54;    // input rows per robot (q, v, targets)
-constexpr int MODEL_PAD_WORDS = 256;  // ModelC padded to 2 KB (multiple of BLOCK 8-byte words)
+constexpr int MODEL_PAD_WORDS = 320;  // ModelC padded to 2.5 KB (multiple of BLOCK 8-byte words)
 constexpr int MODEL_REPLICAS = 256;   // per-block replicas of the model table in HBM
 static_assert(sizeof(wbc::ModelC) <= MODEL_PAD_WORDS * 8 && MODEL_PAD_WORDS % BLOCK == 0, "model padding");
 
@@ -697,15 +697,15 @@ int wbc_set_stream(wbc_handle h, void* hip_stream) {
   return 0;
 }
 
-// variant 0 = auto.  Measured on MI355X (profiles/r02/sweep.md): the 16-lane kernel wins while its n/4
-// wavefronts fit one (ID: GI-bound) or two (MPTC/PC) per SIMD of the 256 CUs; beyond that the quad
+// variant 0 = auto.  Measured on MI355X (profiles/r01/hex_sweep.md): the 16-lane kernel wins while its n/4
+// wavefronts fit two (ID) or four (MPTC/PC) per SIMD of the 256 CUs; beyond that the quad
 // kernel's lower total instruction count wins.  The torque box and the CLF law exist on the
 // lane-per-robot kernel only.
 static int pick_variant(const wbc_handle_s* h, int n) {
   if (h->variant) return h->variant;
   if (h->lane_only) return 1;
   const int hex_waves = (n + 3) / 4;
-  const int limit = 1024 * (h->kind == WBC_KIND_ID ? 1 : 2);
+  const int limit = 1024 * (h->kind == WBC_KIND_ID ? 2 : 4);
   return hex_waves <= limit ? 3 : 2;
 }
 

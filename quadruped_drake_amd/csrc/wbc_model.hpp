@@ -27,6 +27,7 @@ inline int model_from_flat(const double* f, ModelC* m) {
       if (ax < 0) return -1;
       L.axis = ax;
       L.sgn = a[ax] > 0 ? 1.0 : -1.0;
+      for (int i = 0; i < 3; i++) L.axv[i] = (i == ax) ? L.sgn : 0.0;
       L.mass = f[k++];
       for (int i = 0; i < 3; i++) L.mc[i] = L.mass * f[k++];
       for (int i = 0; i < 6; i++) L.I[i] = f[k++];

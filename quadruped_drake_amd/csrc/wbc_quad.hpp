@@ -445,7 +445,7 @@ WBC_HD int quad_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned m
         qd[k] = in(25 + row);
       }
       WBC_CUT_AT(13, sn[0] + sn[1] + sn[2] + cs[0] + cs[1] + cs[2] + qd[1] + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1] + bI[3] + R0[5])
-      leg_fk(m, l, R0, sn, cs, K);
+      leg_fk_vec(m, l, R0, sn, cs, K);
     }
     WBC_CUT_AT(7, K.rf(0) + K.r(1, 1) + K.Iw(2, 3) + K.mcw(0, 2) + K.ax(2, 0) + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1] + qd[0])
     WBC_STAMP(2);

@@ -57,6 +57,33 @@
 
 namespace wbc {
 
+// 1/x and sqrt(x) for well-scaled positive-magnitude arguments (pivots, norms): hardware seed + Newton steps
+// instead of the IEEE division / sqrt expansions (~15 instructions each with scaling and fix-up, which
+// only matter for denormal or huge inputs).  Accurate to ~1 ulp; 0, inf and NaN propagate to inf/NaN
+// results that every caller discards through a select.  Host: the exact operations.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(WBC_NO_FAST_MATH)
+__device__ __forceinline__ double fast_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double fast_sqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);          // ~2^-26 relative
+  double g = x * y, hh = 0.5 * y;               // g ~ sqrt(x), hh ~ 1/(2 sqrt(x))
+  double e = __builtin_fma(-hh, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  hh = __builtin_fma(hh, e, hh);
+  e = __builtin_fma(-g, g, x);                  // residual
+  g = __builtin_fma(e, hh, g);
+  return (x > 0.0) ? g : 0.0;
+}
+#else
+WBC_HD double fast_rcp(double x) { return 1.0 / x; }
+WBC_HD double fast_sqrt(double x) { return sqrt(x); }
+#endif
+
 // one range reduction for both (the f64 sin/cos are long software routines on the GPU)
 WBC_HD void wbc_sincos(double x, double& s, double& c) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -79,6 +106,7 @@ struct LinkC {
   double mass;
   double mc[3];   // mass * com (first moment, link frame)
   double I[6];    // about the link origin, link frame: xx yy zz xy xz yz
+  double axv[3];  // sgn * e_axis: the same joint axis as a vector (select-free kinematics, leg_fk_vec)
 };
 struct ModelC {
   double base_mass, base_mc[3], base_I[6];
@@ -107,6 +135,7 @@ template <class T> WBC_HD void symv(const T* S, const T* x, T* y) {
   T c = S[4] * x[0] + S[5] * x[1] + S[2] * x[2];
   y[0] = a; y[1] = b; y[2] = c;
 }
+template <class T> WBC_HD void mm3(const T* A, const T* B, T* C);
 // y = R x, R row-major 3x3
 template <class T> WBC_HD void rotv(const T* R, const T* x, T* y) {
   T a = R[0] * x[0] + R[1] * x[1] + R[2] * x[2];
@@ -194,6 +223,43 @@ WBC_HD void leg_fk(const ModelC& m, int l, const T* R0, const T* sn, const T* cs
       R[3 * i + b] = cb * co + cc * s;
       R[3 * i + c] = cc * co - cb * s;
     }
+    T mc[3] = {T(L.mc[0]), T(L.mc[1]), T(L.mc[2])}, mcw[3], Iw[6];
+    rotv(R, mc, mcw);
+    rot_inertia(R, L.I, Iw);
+    for (int i = 0; i < 3; i++) K.mcw(k, i) = mcw[i];
+    for (int i = 0; i < 6; i++) K.Iw(k, i) = Iw[i];
+  }
+  T fo[3] = {T(m.foot_off[l][0]), T(m.foot_off[l][1]), T(m.foot_off[l][2])}, t[3];
+  rotv(R, fo, t);
+  for (int i = 0; i < 3; i++) K.rf(i) = p[i] + t[i];
+}
+
+// The same forward kinematics without register-array indexing by the (run-time) axis number: the joint
+// rotation is applied as a 3x3 product with Rl = diag(a_i^2 + c (1 - a_i^2)) + s [a]x  (a = +-e_axis,
+// so the diagonal is exactly 1 or c).  leg_fk's R[3*i + axis] accesses compile to select trees on the
+// GPU (~800 v_cndmask per leg, profiles/r02); this form is ~120 plain FMAs.
+template <class T, class KinT>
+WBC_HD void leg_fk_vec(const ModelC& m, int l, const T* R0, const T* sn, const T* cs, KinT& K) {
+  T R[9];
+  for (int i = 0; i < 9; i++) R[i] = R0[i];
+  T p[3] = {T(0.0), T(0.0), T(0.0)};
+  for (int k = 0; k < 3; k++) {
+    const LinkC& L = m.link[l][k];
+    T off[3] = {T(L.off[0]), T(L.off[1]), T(L.off[2])}, t[3];
+    rotv(R, off, t);
+    for (int i = 0; i < 3; i++) { p[i] = p[i] + t[i]; K.r(k, i) = p[i]; }
+    const T a0 = T(L.axv[0]), a1 = T(L.axv[1]), a2 = T(L.axv[2]);
+    for (int i = 0; i < 3; i++) K.ax(k, i) = R[3 * i] * a0 + R[3 * i + 1] * a1 + R[3 * i + 2] * a2;
+    const T s = sn[k], c = cs[k];
+    const T q0 = a0 * a0, q1 = a1 * a1, q2 = a2 * a2;
+    T Rl[9];
+    Rl[0] = q0 + c * (T(1.0) - q0); Rl[4] = q1 + c * (T(1.0) - q1); Rl[8] = q2 + c * (T(1.0) - q2);
+    Rl[1] = T(0.0) - s * a2; Rl[2] = s * a1;
+    Rl[3] = s * a2;          Rl[5] = T(0.0) - s * a0;
+    Rl[6] = T(0.0) - s * a1; Rl[7] = s * a0;
+    T Rn[9];
+    mm3(R, Rl, Rn);
+    for (int i = 0; i < 9; i++) R[i] = Rn[i];
     T mc[3] = {T(L.mc[0]), T(L.mc[1]), T(L.mc[2])}, mcw[3], Iw[6];
     rotv(R, mc, mcw);
     rot_inertia(R, L.I, Iw);
