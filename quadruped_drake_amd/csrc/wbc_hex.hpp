@@ -44,6 +44,7 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
     }
     const double s2 = qo.bcast16(t, piv);
     const double rkk = qo.bcast16(Rcol[k], piv);
+    // (the hardware-seeded fast_sqrt / fast_rcp of the active set were tried here: the kernel then spills)
     const double nrm = sqrt(rkk * rkk + s2);
     const double alpha = (rkk > 0.0) ? -nrm : nrm;
     const double v0 = rkk - alpha;
@@ -736,14 +737,19 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       }
       // column lanes: vrow_own = [swing] Lx_s[sub] + sum_i lx_i B[i][col];  rhs lanes: the same dot gives vconst
       vrow_own = (colv && !ct) ? pick3(sb, Lx_s[0], Lx_s[1], Lx_s[2]) : 0.0;
+      // Lambda_bb = G_b - sum_l C_l is symmetric (a task-space inertia): only the upper triangle is formed
+      // (21 instead of 36 leg sums), the lower one is mirrored from the rows already done
+      double Lup[6][6];
 #pragma unroll
       for (int i = 0; i < 6; i++) {
         double Lrow[6];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
+          if (j < i) { Lrow[j] = Lup[j][i]; continue; }
           double c = A[i] * Y[j] + A[6 + i] * Y[6 + j] + A[12 + i] * Y[12 + j];
           if (ct) c += Y[i] * MiY[j] + Y[6 + i] * MiY[6 + j] + Y[12 + i] * MiY[12 + j];
           Lrow[j] = pk.get(PK_GS + 6 * i + j) - qo.legs_sum(c);
+          Lup[i][j] = Lrow[j];
         }
         double ls = 0.0, lx = 0.0, lb = 0.0;
 #pragma unroll

@@ -562,18 +562,16 @@ __global__ void wbc_integrate_kernel(int n, int ld, double dt, double* __restric
   for (int r = 0; r < 12; r++) q[(size_t)(7 + r) * ld + i] += dt * vn[6 + r];
 }
 
-// slot 0 <- sum / max over all slots (one block of 64 lanes)
+// out <- sum / max over all slots: one 64-lane block per statistics word
 __global__ void wbc_stats_reduce_kernel(StatsDev* __restrict__ st, StatsDev* __restrict__ out) {
-  constexpr int NW = sizeof(StatsDev) / 8;  // 22 words; word 4 is the max (bit pattern of a non-negative double)
-  for (int w = 0; w < NW; w++) {
-    double acc = 0.0;
-    for (int sl = threadIdx.x; sl < STAT_SLOTS; sl += 64) {
-      const double x = reinterpret_cast<const double*>(st + sl)[w];
-      acc = (w == 4) ? fmax(acc, x) : acc + x;
-    }
-    acc = (w == 4) ? wave_max(acc) : wave_sum(acc);
-    if (threadIdx.x == 0) reinterpret_cast<double*>(out)[w] = acc;
+  const int w = blockIdx.x;  // word 4 is the max (bit pattern of a non-negative double)
+  double acc = 0.0;
+  for (int sl = threadIdx.x; sl < STAT_SLOTS; sl += 64) {
+    const double x = reinterpret_cast<const double*>(st + sl)[w];
+    acc = (w == 4) ? fmax(acc, x) : acc + x;
   }
+  acc = (w == 4) ? wave_max(acc) : wave_sum(acc);
+  if (threadIdx.x == 0) reinterpret_cast<double*>(out)[w] = acc;
 }
 
 __global__ void wbc_advance_time_kernel(int n, double dt, double* __restrict__ time) {
@@ -697,16 +695,15 @@ int wbc_set_stream(wbc_handle h, void* hip_stream) {
   return 0;
 }
 
-// variant 0 = auto.  Measured on MI355X (profiles/r01/hex_sweep.md): the 16-lane kernel wins while its n/4
-// wavefronts fit two (ID) or four (MPTC/PC) per SIMD of the 256 CUs; beyond that the quad
-// kernel's lower total instruction count wins.  The torque box and the CLF law exist on the
+// variant 0 = auto.  Measured on MI355X (profiles/r01/hex_sweep.md): the 16-lane kernel wins at every batch
+// size for MPTC/PC; for the (active-set-bound) ID law it wins while its n/4 wavefronts fit two per SIMD of
+// the 256 CUs, beyond that the quad kernel's lower total instruction count wins.  The torque box and the CLF law exist on the
 // lane-per-robot kernel only.
 static int pick_variant(const wbc_handle_s* h, int n) {
   if (h->variant) return h->variant;
   if (h->lane_only) return 1;
-  const int hex_waves = (n + 3) / 4;
-  const int limit = 1024 * (h->kind == WBC_KIND_ID ? 2 : 4);
-  return hex_waves <= limit ? 3 : 2;
+  if (h->kind != WBC_KIND_ID) return 3;
+  return (n + 3) / 4 <= 2048 ? 3 : 2;
 }
 
 static int launch(wbc_handle h, int n, int ld, const double* q, const double* v, const double* tg,
@@ -823,7 +820,7 @@ int wbc_stats_get(wbc_handle h, wbc_stats* out) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   StatsDev s;
-  hipLaunchKernelGGL(wbc_stats_reduce_kernel, dim3(1), dim3(64), 0, h->stream, h->d_stats, h->d_stats + STAT_SLOTS);
+  hipLaunchKernelGGL(wbc_stats_reduce_kernel, dim3(sizeof(StatsDev) / 8), dim3(64), 0, h->stream, h->d_stats, h->d_stats + STAT_SLOTS);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipMemcpy(&s, h->d_stats + STAT_SLOTS, sizeof s, hipMemcpyDeviceToHost));
