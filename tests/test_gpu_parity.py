@@ -203,6 +203,24 @@ def test_full_size_properties(cfg, n):
     ctrl.close()
 
 
+@pytest.mark.parametrize("kind,cfg", [("mptc", 3), ("id", 2), ("pc", 3)])
+def test_three_kernel_mappings_agree_at_full_size(kind, cfg):
+    """The lane-, quad- and 16-lane-per-robot kernels are three independent parallelisations of the same tick
+    (different QR distribution, different active-set bookkeeping): at N = 4096 they agree to solver tolerance
+    and the friction rows hold."""
+    from quadruped_drake_amd import workloads
+    b = workloads.make_batch(cfg, n=4096)
+    out = {v: gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"], variant=v)
+           for v in ("hex", "quad", "lane")}
+    for v in out:
+        assert (out[v][2] == 0).all()
+    assert rel_err(out["hex"][0], out["lane"][0]).max() < TOL
+    assert rel_err(out["quad"][0], out["lane"][0]).max() < TOL
+    assert np.allclose(out["hex"][1], out["lane"][1], rtol=1e-5, atol=1e-6)
+    if kind == "pc":
+        assert (out["hex"][1][3] <= 1e-9).all()          # Vdot <= 0 is a hard row of the PC law
+
+
 def test_sub_batch_with_leading_dimension():
     """ld > n: a shard of a larger SoA array is stepped in place (what a multi-GPU shard does)."""
     torch = _torch()
