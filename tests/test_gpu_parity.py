@@ -218,7 +218,9 @@ def test_three_kernel_mappings_agree_at_full_size(kind, cfg):
     assert rel_err(out["quad"][0], out["lane"][0]).max() < TOL
     assert np.allclose(out["hex"][1], out["lane"][1], rtol=1e-5, atol=1e-6)
     if kind == "pc":
-        assert (out["hex"][1][3] <= 1e-9).all()          # Vdot <= 0 is a hard row of the PC law
+        # Vdot <= 0 is a hard row of the PC law; it holds to the active set's feasibility tolerance
+        # 1e-13 (1 + |z|_inf) in normalised units, i.e. times |dVdot/dz| ~ 1e2..1e4 in Vdot units
+        assert (out["hex"][1][3] <= 1e-7).all() and (out["quad"][1][3] <= 1e-7).all()
 
 
 def test_sub_batch_with_leading_dimension():
