@@ -20,6 +20,11 @@
 // emulation in tools/host_tick.cpp for CPU-side validation.
 #pragma once
 #include "wbc_quad.hpp"
+// WBC_QRF bit 0: hardware-seeded sqrt in the Householder steps; bit 1: the same for the reciprocal (measured:
+// bit 1 makes the MPTC kernel spill, bit 0 saves ~240 instructions; profiles/r01/hex_cuts.md)
+#ifndef WBC_QRF
+#define WBC_QRF 1
+#endif
 
 namespace wbc {
 
@@ -44,11 +49,18 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
     }
     const double s2 = qo.bcast16(t, piv);
     const double rkk = qo.bcast16(Rcol[k], piv);
-    // (the hardware-seeded fast_sqrt / fast_rcp of the active set were tried here: the kernel then spills)
+#if WBC_QRF & 1
+    const double nrm = fast_sqrt(rkk * rkk + s2);
+#else
     const double nrm = sqrt(rkk * rkk + s2);
+#endif
     const double alpha = (rkk > 0.0) ? -nrm : nrm;
     const double v0 = rkk - alpha;
-    const double beta = (s2 > 0.0) ? 1.0 / (nrm * (nrm + fabs(rkk))) : 0.0;  // = 2 / (s2 + v0^2); empty column: no-op
+#if WBC_QRF & 2
+    const double beta = (s2 > 0.0) ? fast_rcp(nrm * (nrm + fabs(rkk))) : 0.0;
+#else
+    const double beta = (s2 > 0.0) ? 1.0 / (nrm * (nrm + fabs(rkk))) : 0.0;
+#endif  // = 2 / (s2 + v0^2); empty column: no-op
     const double s = (v0 * Rcol[k] + t) * beta;
     Rcol[k] -= s * v0;
 #pragma unroll
@@ -105,16 +117,17 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   int p = -1;
   double sp = 0.0, up = 0.0, dnp = 1.0;
   const double INF = __builtin_huge_val();
+  // feasibility tolerance from the scale of the unconstrained minimiser (the iterates stay on that scale)
+  const double tol = 1e-13 * (1.0 + qo.max16(fabs(z)));
   for (int trip = 0; trip < maxit; trip++) {
     if (!done && need_pick) {
-      // most violated inactive row (argmin of the tracked values) and, independently, the tolerance
-      const double zinf = qo.max16(fabs(z));
+      // most violated inactive row: argmin of the tracked values
       sp = INF;
       p = -1;
       if (ct && !((active >> h) & 1u)) { sp = sh_; p = h; }
       qo.argmin16(sp, p);
       if (pc && !((active >> 16) & 1u) && spc < sp) { sp = spc; p = 16; }
-      if (!(sp < -1e-13 * (1.0 + zinf))) p = -1;
+      if (!(sp < -tol)) p = -1;
       if (p < 0) {
         done = true;
       } else {
@@ -152,13 +165,18 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     }
     r_h = (pos_h >= 0) ? r_h : 0.0;
     if (PC) r_pc = (pos_pc >= 0) ? r_pc : 0.0;
-    // blocking multiplier: min over active rows with r > 0 of u / r
-    double t1 = (pos_h >= 0 && r_h > 0.0) ? u_h * fast_rcp(r_h) : INF;
-    int hd = (t1 < INF) ? h : -1;
-    qo.argmin16(t1, hd);
-    if (PC) {
-      const double c = (pos_pc >= 0 && r_pc > 0.0) ? u_pc * fast_rcp(r_pc) : INF;
-      if (c < t1) { t1 = c; hd = 16; }
+    // blocking multiplier: min over active rows with r > 0 of u / r (nothing to do while no row is active
+    // anywhere in the wavefront -- every robot's first trip)
+    double t1 = INF;
+    int hd = -1;
+    if (qo.wave_max_int(q) > 0) {
+      t1 = (pos_h >= 0 && r_h > 0.0) ? u_h * fast_rcp(r_h) : INF;
+      hd = (t1 < INF) ? h : -1;
+      qo.argmin16(t1, hd);
+      if (PC) {
+        const double c = (pos_pc >= 0 && r_pc > 0.0) ? u_pc * fast_rcp(r_pc) : INF;
+        if (c < t1) { t1 = c; hd = 16; }
+      }
     }
     const bool have_t1 = hd >= 0;
     const bool dependent = !(d2n > 1e-22 * dnp) || q == NZ;
@@ -727,14 +745,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     }
     double Acol[18];
     {
-      double A[18];  // Ji Jfb
-      for (int i = 0; i < 3; i++) {
-        const double a0 = Ji[3 * i], a1 = Ji[3 * i + 1], a2 = Ji[3 * i + 2];
-        A[6 * i + 0] = -(a1 * rf[2] - a2 * rf[1]);
-        A[6 * i + 1] = -(a2 * rf[0] - a0 * rf[2]);
-        A[6 * i + 2] = -(a0 * rf[1] - a1 * rf[0]);
-        A[6 * i + 3] = a0; A[6 * i + 4] = a1; A[6 * i + 5] = a2;
-      }
+      // (Ji Jfb)' Y = [ rf x M ; M ] with M = Ji' Y (= Mt_bl, already formed): column j of the top block is rf x M[:, j]
       // column lanes: vrow_own = [swing] Lx_s[sub] + sum_i lx_i B[i][col];  rhs lanes: the same dot gives vconst
       vrow_own = (colv && !ct) ? pick3(sb, Lx_s[0], Lx_s[1], Lx_s[2]) : 0.0;
       // Lambda_bb = G_b - sum_l C_l is symmetric (a task-space inertia): only the upper triangle is formed
@@ -746,7 +757,8 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
 #pragma unroll
         for (int j = 0; j < 6; j++) {
           if (j < i) { Lrow[j] = Lup[j][i]; continue; }
-          double c = A[i] * Y[j] + A[6 + i] * Y[6 + j] + A[12 + i] * Y[12 + j];
+          const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+          double c = (i < 3) ? rf[i1] * Mt_bl[3 * j + i2] - rf[i2] * Mt_bl[3 * j + i1] : Mt_bl[3 * j + (i - 3)];
           if (ct) c += Y[i] * MiY[j] + Y[6 + i] * MiY[6 + j] + Y[12 + i] * MiY[12 + j];
           Lrow[j] = pk.get(PK_GS + 6 * i + j) - qo.legs_sum(c);
           Lup[i][j] = Lrow[j];
