@@ -379,6 +379,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   const bool ct = (mask >> l) & 1u;
   const bool colv = sb < 3;  // owns a z-space column (else: the right-hand-side / ab0 column)
   int status = ST_OK;
+  WBC_HCUT_AT(0, in(0) + in(20) + in(40) + in(37 + 18 + 9 * l + sb) + mu + mass_scale + m.gravity)
   // ---------------- state (replicated on the 16 lanes)
   double R0[9];
   {

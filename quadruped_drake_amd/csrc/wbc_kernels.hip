@@ -431,14 +431,12 @@ constexpr int HROBOTS = BLOCK / 16;  // robots per 64-lane block
 // ordinary, schedulable LDS loads
 struct ParkLds {
   double* a;
-  const double* r;
-  __device__ __forceinline__ explicit ParkLds(double* p) : a(p) {
-    const double* q = p;
-    asm volatile("" : "+v"(q));
-    r = q;
-  }
+  int z;  // an opaque zero: reads go through a[z + i], which the compiler can neither forward from the stores
+          // nor demote to a generic (flat) access -- laundering the POINTER loses the LDS address space and
+          // turns every read into a flat_load with vmcnt waits (measured, profiles/r01/hex_cuts.md)
+  __device__ __forceinline__ explicit ParkLds(double* p) : a(p), z(0) { asm volatile("" : "+v"(z)); }
   __device__ __forceinline__ void put(int i, double v) { a[i] = v; }
-  __device__ __forceinline__ double get(int i) const { return r[i]; }
+  __device__ __forceinline__ double get(int i) const { return a[z + i]; }
 };
 
 template <int KIND>

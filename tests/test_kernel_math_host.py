@@ -125,6 +125,24 @@ def test_hex_all_contact_masks_on_host():
         assert np.allclose(met, met_o, rtol=1e-7, atol=1e-8)
 
 
+def test_straight_knee_is_reported_not_solved():
+    """Known limit of the reduced (task-coordinate) formulation: it inverts every leg's 3x3 foot Jacobian, so a
+    fully straight knee (kinematic singularity) is reported as status 2 with zero torques by all three kernel
+    mappings -- the dense oracle (like the reference's full QP) still solves it.  DESIGN.md section 3."""
+    b = workloads.make_batch(3, n=8)
+    t = orc.load_model_json("mini_cheetah")
+    q = b["q"].copy()
+    q[7 + 2, 0] = 0.0          # LF knee straight
+    q[7 + 3 * 2 + 2, 1] = 0.0  # LH knee straight
+    for kind in ("mptc", "id"):
+        for kw in ({}, {"quad": True}, {"hexv": True}):
+            tau, met, st, it = ht.run(kind, t["flat"], q, b["v"], b["targets"], b["mask"], **kw)
+            assert st.tolist() == [2, 2, 0, 0, 0, 0, 0, 0]
+            assert (tau[:, :2] == 0).all() and np.isfinite(tau).all()
+        _, _, st_o = orc.step_batch(kind, orc.model("mini_cheetah"), orc.params(kind), q, b["v"], b["targets"], b["mask"])
+        assert (st_o == 0).all()
+
+
 def test_pc_enforces_passivity_where_mptc_does_not():
     """pc_controller.py: Vdot <= 0 is a hard row; MPTC only logs Vdot."""
     b = workloads.make_batch(3, n=128)
