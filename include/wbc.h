@@ -46,7 +46,7 @@ extern "C" {
 #define WBC_KIND_ID 0
 #define WBC_KIND_MPTC 1
 #define WBC_KIND_PC 2 /* controllers/pc_controller.py:44-255: MPTC + passivity row Vdot <= 0 */
-#define WBC_KIND_CLF 3 /* controllers/clf_controller.py:48-234: CLF-QP (runs on the lane-per-robot kernel) */
+#define WBC_KIND_CLF 3 /* controllers/clf_controller.py:48-234: CLF-QP (13 reduced variables: z and the slack delta) */
 
 #define WBC_MODEL_FLAT 215
 #define WBC_NQ 19
@@ -148,9 +148,9 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
                 const double* mass_scale, double* tau, double* metrics, int32_t* status, double* vdot);
 
 /* Kernel variant: 0 = auto (default), 1 = lane-per-robot, 2 = quad-per-robot (4 lanes = 4 legs),
- * 3 = 16 lanes (one DPP row) per robot.  All compute the same tick.  Auto: 16-lane for MPTC / PC at any
- * batch size and for ID up to n = 8192 (quad beyond); lane-per-robot when the optional torque box is
- * enabled or the kind is WBC_KIND_CLF (13 reduced variables). */
+ * 3 = 16 lanes (one DPP row) per robot.  All compute the same tick.  Auto: 16-lane for MPTC / PC / CLF at
+ * any batch size and for ID up to n = 8192 (quad beyond); lane-per-robot when the optional torque box is
+ * enabled.  The CLF law has no quad-per-robot kernel. */
 int wbc_set_variant(wbc_handle h, int variant);
 /* The variant (1, 2 or 3) a wbc_step of n instances would run. */
 int wbc_variant_for(wbc_handle h, int n);

@@ -252,7 +252,8 @@ class PCController(BatchedController):
 
 
 class CLFController(BatchedController):
-    """controllers/clf_controller.py:3-234 (CLF-QP inverse dynamics), batched; lane-per-robot kernel."""
+    """controllers/clf_controller.py:3-234 (CLF-QP inverse dynamics), batched; 13 reduced variables [z; delta]
+    (16-lane kernel: the slack lives on a spare sub-lane; also on the lane-per-robot kernel)."""
     kind = _lib.KIND_CLF
 
 

@@ -28,17 +28,19 @@
 
 namespace wbc {
 
-// lane (within the 16-lane row) that owns z-space column / row k = 3*leg + coordinate
-WBC_HD constexpr int hex_lane(int k) { return 4 * (k / 3) + (k % 3); }
+// lane (within the 16-lane row) that owns z-space column / row k = 3*leg + coordinate; the CLF law's 13th
+// reduced variable (the slack delta, k = 12) lives on the spare sub-lane 3 of leg 1
+enum { HEX_DELTA_LANE = 7 };
+WBC_HD constexpr int hex_lane(int k) { return k < 12 ? 4 * (k / 3) + (k % 3) : HEX_DELTA_LANE; }
 
 // Distributed Householder append: fold P dense rows into the upper-triangular factor.
 // Lane hex_lane(c) holds column c: Rcol[12], Acol[P]; the lanes with sub == 3 hold the right-hand side
 // as one more column.  Already-pivoted columns are left with O(ulp) residue below the diagonal of R
 // (never read) instead of being zeroed: no per-step predication.
-template <class Q, int P>
+template <class Q, int P, int NV = NZ>
 WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
 #pragma unroll
-  for (int k = 0; k < NZ; k++) {
+  for (int k = 0; k < NV; k++) {
     const int piv = hex_lane(k);
     double col[P];
     double t = 0.0;
@@ -84,32 +86,33 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
 //     Givens rotations to the slots of (Jr, Dh, Wr) alike and renumbers the positions;
 //   * the blocking multiplier is a lane-parallel ratio + argmin.
 // Nothing lives in LDS and the loop has no divergent inner branches (profiles/r02/hex_cuts.md).
-// The optional PC row (index 16) is dense: its image/value/multiplier are replicated on all lanes.
-template <class Q, bool PC>
+// The optional dense row (index 16: the PC law's Vdot <= 0, the CLF law's CLF row) has its image / value /
+// multiplier replicated on all lanes.  NV = 13 for the CLF law (slack delta on lane HEX_DELTA_LANE).
+template <class Q, bool PC, int NV = NZ>
 WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, double inv_s, int* iters_out,
                   double vrow_own = 0.0, double vc = 0.0, double pc_inv = 0.0) {
   const int sb = h & 3;
   const bool pc = PC && pc_inv > 0.0;
   const double sg = (sb & 1) ? inv_s : -inv_s;   // own row: n_h = sg * e_(leg, sb>>1) + mu_n * e_(leg, 2)
-  double Dh[NZ], sh_, dnh = 0.0;
+  double Dh[NV], sh_, dnh = 0.0;
 #pragma unroll
-  for (int k = 0; k < NZ; k++) {
+  for (int k = 0; k < NV; k++) {
     Dh[k] = sg * qo.leg_pairs(Jr[k]) + mu_n * qo.leg_bcast(Jr[k], 2);
     dnh += Dh[k] * Dh[k];
   }
   sh_ = sg * qo.leg_pairs(z) + mu_n * qo.leg_bcast(z, 2);
-  double Dpc[NZ], spc = 0.0, dnpc = 0.0, u_pc = 0.0;
+  double Dpc[NV], spc = 0.0, dnpc = 0.0, u_pc = 0.0;
   int pos_pc = -1;
   if (PC) {
     const double npl = -vrow_own * pc_inv;
 #pragma unroll
-    for (int k = 0; k < NZ; k++) { Dpc[k] = qo.sum16(Jr[k] * npl); dnpc += Dpc[k] * Dpc[k]; }
+    for (int k = 0; k < NV; k++) { Dpc[k] = qo.sum16(Jr[k] * npl); dnpc += Dpc[k] * Dpc[k]; }
     spc = -(qo.sum16(vrow_own * z) + vc) * pc_inv;
   }
-  double u_h = 0.0, Wr[NZ], Wpc[NZ];
+  double u_h = 0.0, Wr[NV], Wpc[NV];
   int pos_h = -1;
 #pragma unroll
-  for (int k = 0; k < NZ; k++) { Wr[k] = 0.0; Wpc[k] = 0.0; }
+  for (int k = 0; k < NV; k++) { Wr[k] = 0.0; Wpc[k] = 0.0; }
   int q = 0, iters = 0, status = ST_OK;
   unsigned active = 0u;
   const int maxit = 200;
@@ -140,9 +143,9 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     if (qo.wave_all(done)) break;
     if (done) continue;
     iters++;
-    double d[NZ], dm[NZ], d2n = 0.0;
+    double d[NV], dm[NV], d2n = 0.0;
 #pragma unroll
-    for (int k = 0; k < NZ; k++) {
+    for (int k = 0; k < NV; k++) {
       d[k] = qo.bcast16d(Dh[k], p & 15);
       if (PC) d[k] = (p == 16) ? Dpc[k] : d[k];
       dm[k] = (k >= q) ? d[k] : 0.0;
@@ -150,7 +153,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     }
     double zd = 0.0, sd = 0.0, sdpc = 0.0;
 #pragma unroll
-    for (int k = 0; k < NZ; k++) {
+    for (int k = 0; k < NV; k++) {
       zd += Jr[k] * dm[k];
       sd += Dh[k] * dm[k];
       if (PC) sdpc += Dpc[k] * dm[k];
@@ -158,7 +161,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     // dual step direction r = R^-1 d[0:q]: every active row's lane holds its row of W = R^-1
     double r_h = 0.0, r_pc = 0.0;
 #pragma unroll
-    for (int k = 0; k < NZ; k++) {
+    for (int k = 0; k < NV; k++) {
       const double d1 = d[k] - dm[k];
       r_h += Wr[k] * d1;
       if (PC) r_pc += Wpc[k] * d1;
@@ -179,7 +182,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       }
     }
     const bool have_t1 = hd >= 0;
-    const bool dependent = !(d2n > 1e-22 * dnp) || q == NZ;
+    const bool dependent = !(d2n > 1e-22 * dnp) || q == NV;
     const double t2 = -sp * fast_rcp(d2n);   // n_p' J2 J2' n_p = |d[q:]|^2
     if (dependent && !have_t1) { status = ST_SINGULAR; done = true; continue; }
     const bool full = !dependent && (!have_t1 || !(t1 < t2));
@@ -198,16 +201,16 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       // one Householder reflection H on d[q:] (H d2 = alpha e_q);  J2 <- J2 H on the own row, images alike
       double dq = 0.0;
 #pragma unroll
-      for (int k = 0; k < NZ; k++) dq = (k == q) ? d[k] : dq;
+      for (int k = 0; k < NV; k++) dq = (k == q) ? d[k] : dq;
       const double nrm = fast_sqrt(d2n);
       const double alpha = (dq > 0.0) ? -nrm : nrm;
       const double vq = dq - alpha;
       const double ia = fast_rcp(alpha);
       const double beta = fast_rcp(nrm * (nrm + fabs(dq)));   // 2 / (v'v)
       double w = 0.0, wd = 0.0, wp = 0.0;
-      double hv[NZ];
+      double hv[NV];
 #pragma unroll
-      for (int k = 0; k < NZ; k++) {
+      for (int k = 0; k < NV; k++) {
         hv[k] = (k == q) ? vq : dm[k];
         w += Jr[k] * hv[k];
         wd += Dh[k] * hv[k];
@@ -215,7 +218,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       }
       w *= beta; wd *= beta; wp *= beta;
 #pragma unroll
-      for (int k = 0; k < NZ; k++) {
+      for (int k = 0; k < NV; k++) {
         Jr[k] -= w * hv[k];
         Dh[k] -= wd * hv[k];
         if (PC) Dpc[k] -= wp * hv[k];
@@ -225,7 +228,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       {
         const double wq = mine ? ia : -r_h * ia;
 #pragma unroll
-        for (int k = 0; k < NZ; k++) Wr[k] = (k == q) ? wq : Wr[k];
+        for (int k = 0; k < NV; k++) Wr[k] = (k == q) ? wq : Wr[k];
       }
       u_h = mine ? up : u_h;
       pos_h = mine ? q : pos_h;
@@ -233,7 +236,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         const bool pm = (p == 16);
         const double wq = pm ? ia : -r_pc * ia;
 #pragma unroll
-        for (int k = 0; k < NZ; k++) Wpc[k] = (k == q) ? wq : Wpc[k];
+        for (int k = 0; k < NV; k++) Wpc[k] = (k == q) ? wq : Wpc[k];
         u_pc = pm ? up : u_pc; pos_pc = pm ? q : pos_pc;
       }
       active |= (1u << p);
@@ -251,19 +254,19 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         u_h = mine ? 0.0 : u_h;
         pos_h = mine ? -1 : ((pos_h > ld) ? pos_h - 1 : pos_h);
 #pragma unroll
-        for (int k = 0; k < NZ; k++) Wr[k] = mine ? 0.0 : Wr[k];
+        for (int k = 0; k < NV; k++) Wr[k] = mine ? 0.0 : Wr[k];
       }
       if (PC) {
         const bool pm = (hd == 16);
         u_pc = pm ? 0.0 : u_pc;
         pos_pc = pm ? -1 : ((pos_pc > ld) ? pos_pc - 1 : pos_pc);
 #pragma unroll
-        for (int k = 0; k < NZ; k++) Wpc[k] = pm ? 0.0 : Wpc[k];
+        for (int k = 0; k < NV; k++) Wpc[k] = pm ? 0.0 : Wpc[k];
       }
       q--;
       // columns ld..q-1 now carry one sub-diagonal entry each: rotate rows (j, j+1), j = ld..q-1
 #pragma unroll
-      for (int j = 0; j < NZ - 1; j++) {
+      for (int j = 0; j < NV - 1; j++) {
         if (j >= ld && j < q) {
           // (a, b) = entries (j, j+1) of the column now at position j: the image of the row whose position is j
           const bool here = (pos_h == j);
@@ -377,7 +380,10 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   const int h = qo.lane();
   const int l = h >> 2, sb = h & 3;
   const bool ct = (mask >> l) & 1u;
-  const bool colv = sb < 3;  // owns a z-space column (else: the right-hand-side / ab0 column)
+  constexpr bool MP = (KIND == KIND_MPTC || KIND == KIND_PC);   // task-space passivity laws (xi passes, Lambda)
+  constexpr int NV = (KIND == KIND_CLF) ? NZ + 1 : NZ;          // reduced variables: z (12) [+ slack delta]
+  const bool colv = sb < 3;  // owns a z-space column (else: the right-hand-side / ab0 column, or delta)
+  const bool cold = (KIND == KIND_CLF) && h == HEX_DELTA_LANE;   // owns the delta column (CLF law)
   int status = ST_OK;
   WBC_HCUT_AT(0, in(0) + in(20) + in(40) + in(37 + 18 + 9 * l + sb) + mu + mass_scale + m.gravity)
   // ---------------- state (replicated on the 16 lanes)
@@ -498,7 +504,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       xdt_s[i] = ct ? 0.0 : pd[i] - tpd;
       xdd_s[i] = ct ? 0.0 : tpdd;
     }
-    if (KIND != KIND_ID) {
+    if (MP) {
       double Mli[9];
       inv3(Mf, Mli);
       double t[3], jfb[3];
@@ -522,13 +528,13 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     // Newton-Euler: sub-lanes 0 and 3 run the bias pass h(v) (with gravity); for the MPTC laws
     // sub-lane 1 runs h(v + xi) and sub-lane 2 h(v - xi) (gravity-free):  C xi = 1/4 [h(v+xi) - h(v-xi)].
     {
-      const double c1 = (KIND == KIND_ID) ? 0.0 : ((sb == 1) ? 1.0 : ((sb == 2) ? -1.0 : 0.0));
-      const double gq = (KIND == KIND_ID || sb == 0 || sb == 3) ? gz : 0.0;
+      const double c1 = !MP ? 0.0 : ((sb == 1) ? 1.0 : ((sb == 2) ? -1.0 : 0.0));
+      const double gq = (!MP || sb == 0 || sb == 3) ? gz : 0.0;
       const double wv[3] = {w0[0] + c1 * xdt_b[0], w0[1] + c1 * xdt_b[1], w0[2] + c1 * xdt_b[2]};
       const double qv[3] = {qd[0] + c1 * xi[0], qd[1] + c1 * xi[1], qd[2] + c1 * xi[2]};
       double hq[3], Nq[3], Fq[3];
       leg_rnea<double, true>(mass3, K, wv, qv, gq, hq, Nq, Fq, &D);
-      if (KIND == KIND_ID) {
+      if (!MP) {
         for (int i = 0; i < 3; i++) { hl[i] = hq[i]; hbN[i] = Nq[i]; hbN[3 + i] = Fq[i]; Jdv[i] = D.Jdv[i]; }
       } else {
         double jx[3];
@@ -613,7 +619,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       Gs[i][4] = Mbb[i][4] - qo.legs_sum(a1);
       Gs[i][5] = Mbb[i][5] - qo.legs_sum(a2);
     }
-    if (KIND != KIND_ID)
+    if (MP)
       for (int i = 0; i < 6; i++)
         for (int j = 0; j < 6; j++) pk.put(PK_GS + 6 * i + j, Gs[i][j]);
   }
@@ -641,12 +647,14 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   // ---------------- level-1 rows
   const double eps = sqrt(P.eps2);
   const double sw_b = sqrt(P.w_body), sw_f = sqrt(P.w_foot);
-  double Rcol[NZ];
+  double Rcol[NV];
   double met_err = 0.0;
   for (int i = 0; i < 6; i++) met_err += xt_b[i] * xt_b[i];
   met_err += qo.legs_sum(xt_s[0] * xt_s[0] + xt_s[1] * xt_s[1] + xt_s[2] * xt_s[2]);
   double met_V = 0.0, met_Vdot = 0.0;
   double vrow_own = 0.0, vconst = 0.0;  // Vdot = met_Vdot + vconst + sum over column lanes of vrow_own * z
+  // CLF law (clf_controller.py:48-234): swing-row data of the own row and the CLF row  g . [z; delta] <= ub
+  double clf_dval = 0.0, clf_drhs = 0.0, clf_g = 0.0, clf_ub = 0.0, clf_inv = 0.0, clf_c0 = 0.0, clf_gab0 = 0.0;
   auto init_rcol = [&]()   {
     // diagonal rows: swing leg sqrt(w_foot) (ID) / 0 (MPTC); contact leg eps.  Row 3*leg+sub lives on lane (leg, sub).
     double dval, drhs;
@@ -656,12 +664,14 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     else if (KIND == KIND_ID) {
       const double des = xdd_o - P.Kp_foot * xt_o - P.Kd_foot * xdt_o;
       dval = sw_f; drhs = sw_f * (des - jdv_o);
-    } else { dval = 0.0; drhs = 0.0; }
+    } else if (KIND == KIND_CLF) { dval = clf_dval; drhs = clf_drhs; }
+    else { dval = 0.0; drhs = 0.0; }
 #pragma unroll
     for (int k = 0; k < NZ; k++) {
       const double rk = qo.bcast16(drhs, hex_lane(k));
-      Rcol[k] = colv ? ((hex_lane(k) == h) ? dval : 0.0) : rk;
+      Rcol[k] = colv ? ((hex_lane(k) == h) ? dval : 0.0) : (cold ? 0.0 : rk);
     }
+    if (KIND == KIND_CLF) Rcol[NV - 1] = cold ? sqrt(2.0 * 1000.0) : 0.0;   // w_delta delta^2 = 1/2 (sqrt(2 w) delta)^2  (:73,:206)
   };
   // level-2 rows eps (T z + t0):  T[(l',i)][(l,j)] = Y_l'[i] . B_l[:,j] + delta D_l[i][j].  (Folding them into
   // the level-1 append -- one pass of 12 pivots over 30 rows -- was measured: it spills, profiles/r02.)
@@ -674,7 +684,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       for (int k = 0; k < 6; k++) dotv += qo.bcast16(Yrow[k], src) * bcol[k];
       const double t0r = qo.bcast16(t0_own, src);
       const double dg = (r / 3 == l) ? Dcol[r % 3] : 0.0;
-      A2[r] = colv ? eps * (dotv + dg) : -eps * (t0r + dotv);
+      A2[r] = colv ? eps * (dotv + dg) : (cold ? 0.0 : -eps * (t0r + dotv));
     }
   };
   if (KIND == KIND_ID) {
@@ -682,6 +692,47 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     for (int i = 0; i < 6; i++) Acol[i] = colv ? sw_b * bcol[i] : sw_b * (ades[i] - bcol[i]);
     init_rcol();
     hex_qr_append<Q, 6>(qo, Rcol, Acol);
+  } else if (KIND == KIND_CLF) {
+    // ---------------- CLF-QP in task coordinates, unit weights on every task row (see wbc_tick.hpp for the
+    // lane-per-robot original; gains are the literals of clf_controller.py:65-73)
+    const double Qp_b = 5000.0, Qd_b = 200.0, Qp_f = 200.0, Qd_f = 20.0, rr = 1.0;
+    const double pb12 = sqrt(Qp_b * rr), pb22 = sqrt(rr * (Qd_b + 2.0 * pb12)), pb11 = pb12 * pb22 / rr;   // CARE, closed form (:187)
+    const double pf12 = sqrt(Qp_f * rr), pf22 = sqrt(rr * (Qd_f + 2.0 * pf12)), pf11 = pf12 * pf22 / rr;
+    double V = 0.0, ePFe = 0.0, ub = 0.0, gdot = 0.0, gxdd = 0.0;
+    double Acol[6];
+    for (int i = 0; i < 6; i++) {
+      const double pg = pb12 * xt_b[i] + pb22 * xdt_b[i], gt = 2.0 * pg;
+      V += pb11 * xt_b[i] * xt_b[i] + 2.0 * pb12 * xt_b[i] * xdt_b[i] + pb22 * xdt_b[i] * xdt_b[i];
+      ePFe += pb11 * xt_b[i] * xdt_b[i] + pb12 * xdt_b[i] * xdt_b[i];
+      ub += gt * xdd_b[i];
+      gxdd += gt * xdd_b[i];
+      const double ystar = xdd_b[i] - pg / rr - gt;
+      gdot += gt * bcol[i];   // column lanes: sum_i gt_i B[i][col];  rhs lanes: sum_i gt_i ab0[i]
+      Acol[i] = colv ? bcol[i] : (cold ? 0.0 : ystar - bcol[i]);
+    }
+    // own swing row (lane (leg, sub < 3) of a swing leg)
+    const bool swl = colv && !ct;
+    const double xt = pick3(sb, xt_s[0], xt_s[1], xt_s[2]), xdt = pick3(sb, xdt_s[0], xdt_s[1], xdt_s[2]),
+                 xddn = pick3(sb, xdd_s[0], xdd_s[1], xdd_s[2]), jdv = pick3(sb, Jdv[0], Jdv[1], Jdv[2]);
+    const double pgs = pf12 * xt + pf22 * xdt, gts = swl ? 2.0 * pgs : 0.0;
+    clf_dval = 1.0;
+    clf_drhs = xddn - pgs / rr - jdv - 2.0 * pgs;
+    V += qo.sum16(swl ? pf11 * xt * xt + 2.0 * pf12 * xt * xdt + pf22 * xdt * xdt : 0.0);
+    ePFe += qo.sum16(swl ? pf11 * xt * xdt + pf12 * xdt * xdt : 0.0);
+    const double gs_jx = qo.sum16(gts * (jdv - xddn));   // sum over swing rows of gt (Jdv - xdd_nom)
+    ub -= gs_jx;
+    const bool any_swing = (mask & 0xFu) != 0xFu;
+    const double hb = 0.5 * (pb11 + pb22), db = 0.5 * (pb11 - pb22), evb = hb + sqrt(db * db + pb12 * pb12);
+    const double hf = 0.5 * (pf11 + pf22), df = 0.5 * (pf11 - pf22), evf = hf + sqrt(df * df + pf12 * pf12);
+    const double qmin = any_swing ? Qd_f : Qd_b, pmax = (any_swing && evf > evb) ? evf : evb;   // gamma = min eig Q / max eig P (:188)
+    clf_gab0 = qo.bcast16(gdot, 3);
+    clf_ub = ub - (qmin / pmax) * V - 2.0 * ePFe - clf_gab0;
+    clf_g = colv ? gdot + gts : (cold ? -1.0 : 0.0);
+    clf_inv = 1.0 / sqrt(qo.sum16(clf_g * clf_g));
+    clf_c0 = 2.0 * ePFe - gxdd + gs_jx;
+    met_V = V;
+    init_rcol();
+    hex_qr_append<Q, 6, NV>(qo, Rcol, Acol);
   } else {
     // ---- MPTC in task coordinates (derivation: wbc_tick.hpp / DESIGN.md)
     double MiY[18], Mt_bl[18], Mt_ll[9];
@@ -804,21 +855,21 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   {
     double A2[NZ];
     level2_rows(A2);
-    hex_qr_append<Q, NZ>(qo, Rcol, A2);
+    hex_qr_append<Q, NZ, NV>(qo, Rcol, A2);
   }
   WBC_HCUT_AT(5, Rcol[0] + Rcol[5] + Rcol[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- own row of J = R^-1 and unconstrained minimiser
-  double z, Jr[NZ];
+  double z, Jr[NV];
   {
     const double rown = [&] { double x = 0.0;
 #pragma unroll
-      for (int k = 0; k < NZ; k++) x = (hex_lane(k) == h) ? Rcol[k] : x;
+      for (int k = 0; k < NV; k++) x = (hex_lane(k) == h) ? Rcol[k] : x;
       return x; }();
     const double inv_own = 1.0 / rown;
-    double invd[NZ];
+    double invd[NV];
     double rmax = 0.0, rmin = 0.0;
 #pragma unroll
-    for (int c = 0; c < NZ; c++) {
+    for (int c = 0; c < NV; c++) {
       invd[c] = qo.bcast16(inv_own, hex_lane(c));
       const double a = fabs(invd[c]);   // 1/|R_cc|: max <-> min swap
       if (c == 0 || a > rmax) rmax = a;
@@ -832,12 +883,12 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       *iters_out = 0;
       return status;
     }
-    // my row index rr = 3*l + sb (column lanes).  J[rr][c] = (delta - sum_{k<c} J[rr][k] R[k][c]) / R[c][c]
-    const int rr = 3 * l + sb;
+    // my row index rr = 3*l + sb (column lanes; 12 on the delta lane).  J[rr][c] = (delta_rr,c - sum_{k<c} J[rr][k] R[k][c]) / R[c][c]
+    const int rr = cold ? NZ : 3 * l + sb;
     double zacc = 0.0;
 #pragma unroll
-    for (int c = 0; c < NZ; c++) {
-      double s = (colv && c == rr) ? 1.0 : 0.0;
+    for (int c = 0; c < NV; c++) {
+      double s = ((colv || cold) && c == rr) ? 1.0 : 0.0;
 #pragma unroll
       for (int k = 0; k < c; k++) s -= Jr[k] * qo.bcast16(Rcol[k], hex_lane(c));
       Jr[c] = s * invd[c];
@@ -855,6 +906,9 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       const double vr = colv ? vrow_own : 0.0;
       const double n2 = qo.sum16(vr * vr);
       st = hex_gi<Q, true>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, vr, vconst + met_Vdot, (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0);
+    } else if (KIND == KIND_CLF) {
+      // the CLF row  g . [z; delta] - ub <= 0  is the dense row of the active set (index 16), like PC's Vdot row
+      st = hex_gi<Q, true, NV>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, clf_g, -clf_ub, clf_inv);
     } else {
       st = hex_gi<Q, false>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters);
     }
@@ -883,7 +937,11 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   double res = 0.0;
   if (ct) res = fmax(fabs(z0) - mu * z2, fabs(z1) - mu * z2);
   res = fmax(0.0, qo.max16(res));
-  if (KIND != KIND_ID) {
+  if (KIND == KIND_CLF) {
+    // Vdot = 2 eta'PF eta + 2 eta'PG (J vd + Jdv - xdd_nom)   (clf_controller.py:230)
+    const double vd = clf_c0 + clf_gab0 + qo.sum16(colv ? clf_g * z : 0.0);
+    out_met(0, met_V); out_met(1, met_err); out_met(2, 0.0); out_met(3, vd);
+  } else if (KIND != KIND_ID) {
     met_Vdot += vconst + qo.sum16(colv ? vrow_own * z : 0.0);
     out_met(0, met_V); out_met(1, met_err); out_met(2, 0.0); out_met(3, met_Vdot);
   } else {

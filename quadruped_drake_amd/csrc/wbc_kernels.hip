@@ -638,7 +638,7 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
   h->kind = kind; h->max_batch = max_batch; h->device = device; h->flags = flags;
   h->variant = 0;
   h->torque_box = P.tau_max < 1e300;
-  h->lane_only = h->torque_box || kind == WBC_KIND_CLF;
+  h->lane_only = h->torque_box;   // the optional torque box exists on the lane-per-robot kernel only
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->own_stream = true;
   HIP_TRY(hipMalloc(&h->d_model, (size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8));
@@ -700,7 +700,7 @@ int wbc_set_stream(wbc_handle h, void* hip_stream) {
 static int pick_variant(const wbc_handle_s* h, int n) {
   if (h->variant) return h->variant;
   if (h->lane_only) return 1;
-  if (h->kind != WBC_KIND_ID) return 3;
+  if (h->kind != WBC_KIND_ID) return 3;   // MPTC, PC, CLF (CLF: 16-lane or lane-per-robot only)
   return (n + 3) / 4 <= 2048 ? 3 : 2;
 }
 
@@ -730,21 +730,25 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
                            mask, mu, ms, tau, met, status, d_stats, h->d_vdot);                                         \
     }                                                                                                        \
   } while (0)
+#define WBC_LAUNCH_CLF(KERNEL, GRID)                                                                         \
+  hipLaunchKernelGGL(KERNEL<wbc::KIND_CLF>, GRID, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg,      \
+                     mask, mu, ms, tau, met, status, d_stats, h->d_vdot)
   if (hex) {
     dim3 grid((n + HROBOTS - 1) / HROBOTS);
-    WBC_LAUNCH(wbc_hex_kernel, grid);
+    if (h->kind == WBC_KIND_CLF) WBC_LAUNCH_CLF(wbc_hex_kernel, grid);
+    else WBC_LAUNCH(wbc_hex_kernel, grid);
   } else if (quad) {
     dim3 grid((n + QROBOTS - 1) / QROBOTS);
     WBC_LAUNCH(wbc_quad_kernel, grid);
   } else if (h->kind == WBC_KIND_CLF) {
     dim3 grid((n + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(wbc_tick_kernel<wbc::KIND_CLF>, grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg,
-                       mask, mu, ms, tau, met, status, d_stats, h->d_vdot);
+    WBC_LAUNCH_CLF(wbc_tick_kernel, grid);
   } else {
     dim3 grid((n + BLOCK - 1) / BLOCK);
     WBC_LAUNCH(wbc_tick_kernel, grid);
   }
 #undef WBC_LAUNCH
+#undef WBC_LAUNCH_CLF
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -891,7 +895,8 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
 int wbc_set_variant(wbc_handle h, int variant) {
   if (!h) return misuse("wbc_set_variant: null handle");
   if (variant < 0 || variant > 3) return misuse("wbc_set_variant: 0 = auto, 1 = lane-per-robot, 2 = quad-per-robot, 3 = 16 lanes per robot");
-  if (variant >= 2 && h->lane_only) return misuse("wbc_set_variant: the quad kernel has no torque box / CLF law");
+  if (variant >= 2 && h->lane_only) return misuse("wbc_set_variant: the torque box exists on the lane-per-robot kernel only");
+  if (variant == 2 && h->kind == WBC_KIND_CLF) return misuse("wbc_set_variant: the CLF law runs on the 16-lane or the lane-per-robot kernel");
   h->variant = variant;
   return 0;
 }
@@ -908,7 +913,8 @@ int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_by
   const bool quad = (var == 2);
   const void* fn;
   if (var == 3) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID>
-               : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_kernel<wbc::KIND_MPTC> : (const void*)wbc_hex_kernel<wbc::KIND_PC>;
+               : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_kernel<wbc::KIND_MPTC>
+               : h->kind == WBC_KIND_PC ? (const void*)wbc_hex_kernel<wbc::KIND_PC> : (const void*)wbc_hex_kernel<wbc::KIND_CLF>;
   else if (quad) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_quad_kernel<wbc::KIND_ID>
                : h->kind == WBC_KIND_MPTC ? (const void*)wbc_quad_kernel<wbc::KIND_MPTC> : (const void*)wbc_quad_kernel<wbc::KIND_PC>;
   else fn = h->kind == WBC_KIND_ID ? (const void*)wbc_tick_kernel<wbc::KIND_ID>

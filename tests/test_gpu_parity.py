@@ -30,7 +30,7 @@ def gpu_step(kind, model, q, v, tg, mask, mu=None, ms=None, params=None, max_bat
     cls = {"id": IDController, "mptc": MPTCController, "pc": PCController, "clf": CLFController}[kind]
     n = q.shape[1]
     ctrl = cls(model=model, max_batch=max_batch or n, device=0, params=params, **kw)
-    if not (kind == "clf" and variant in ("quad", "hex")):       # CLF exists on the lane kernel only
+    if not (kind == "clf" and variant == "quad"):       # CLF has no quad kernel: that case runs auto (16-lane)
         ctrl.set_variant(variant)
     up = lambda x: None if x is None else torch.tensor(np.ascontiguousarray(x), device="cuda:0")
     tau, met, st = ctrl.step(up(q), up(v), up(tg), up(mask), up(mu), up(ms))

@@ -359,6 +359,7 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
     const double mui = a.mu ? a.mu[i] : P.mu, msi = a.ms ? a.ms[i] : 1.0;
     if (a.kind == wbc::KIND_ID) st = wbc::hex_tick<HexHost, wbc::KIND_ID>(m, P, qo, in, a.mask[i], mui, msi, pk[h], ot, om, &it);
     else if (a.kind == wbc::KIND_PC) st = wbc::hex_tick<HexHost, wbc::KIND_PC>(m, P, qo, in, a.mask[i], mui, msi, pk[h], ot, om, &it);
+    else if (a.kind == wbc::KIND_CLF) st = wbc::hex_tick<HexHost, wbc::KIND_CLF>(m, P, qo, in, a.mask[i], mui, msi, pk[h], ot, om, &it);
     else st = wbc::hex_tick<HexHost, wbc::KIND_MPTC>(m, P, qo, in, a.mask[i], mui, msi, pk[h], ot, om, &it);
     if (h == 0) { if (a.status) a.status[i] = st; if (a.iters) a.iters[i] = it; }
   };
