@@ -19,7 +19,7 @@
 // `Q` is the communication policy: HexDev (wbc_kernels.hip) on the GPU, a 16-fibre lock-step
 // emulation in tools/host_tick.cpp for CPU-side validation.
 #pragma once
-#include "wbc_quad.hpp"
+#include "wbc_tick.hpp"
 // WBC_QRF bit 0: hardware-seeded sqrt in the Householder steps; bit 1: the same for the reciprocal (measured:
 // bit 1 makes the MPTC kernel spill, bit 0 saves ~240 instructions; profiles/r01/hex_cuts.md)
 #ifndef WBC_QRF
