@@ -151,13 +151,15 @@ def main():
                 "trot contact masks" if cfg != 2 else "4-contact stand"),
                 "instances_per_gpu": n, "seed": shard["seed"],
                 "domain_randomised": mu is not None, "parallelism": "batch-shard x%d" % world},
-            "roofline": {"bound": "valu-f64", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                          "kernel": "%s<%s>" % ({"lane": "wbc_tick_kernel", "hex": "wbc_hex_kernel", "quad": "wbc_quad_kernel"}[used], shard["kind"].upper()),
                          "kernel_ms": ms_per_launch, "flops_per_tick": flops,
                          "hbm": {"achieved_GBs": bpt * n / sec / 1e9, "peak_GBs": PEAK_HBM_GBS,
                                  "frac": bpt * n / sec / 1e9 / PEAK_HBM_GBS, "bytes_per_tick": bpt},
-                         "note": "neither HBM nor MFMA binds this path (SURVEY 8d): FP64 vector ALU roof; HBM fraction stated beside it"},
+                         "bound_detail": "FP64 compute: priced against the dense FP64 peak (78.6 TFLOP/s, the same figure for the "
+                                         "FP64 MFMA and the FP64 vector ALU); the kernel issues vector FMAs, not MFMA (DESIGN.md section 5)",
+                         "note": "HBM does not bind this path (SURVEY 8d): 864 algorithmic bytes per 37.6 kflop tick; HBM fraction stated beside it"},
             "status_nonzero": int((status != 0).sum()),
             "rollout_stats": {k: st[k] for k in ("ticks", "status_nonzero", "iters_sum", "tau_abs_max")},
             "kernel_info": ctrl.kernel_info(),

@@ -446,40 +446,39 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
                const uint8_t* __restrict__ mask, const double* __restrict__ mu,
                const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
                int32_t* __restrict__ status, StatsDev* __restrict__ stats, double* __restrict__ vdot) {
+  constexpr int PER_LANE = (NIN * HROBOTS + BLOCK - 1) / BLOCK;   // 6 input words per lane
   __shared__ double mbuf[MODEL_PAD_WORDS];
-  __shared__ double inbuf[NIN * HROBOTS];
+  __shared__ double inbuf[PER_LANE * BLOCK];                      // 91 rows x 4 robots, padded to whole lanes
   __shared__ double parkbuf[HROBOTS * wbc::PK_N];
   const int slot = threadIdx.x >> 4;
   const int i = blockIdx.x * HROBOTS + slot;
   const bool live = i < n;
   const int ii = live ? i : (n - 1);
-  {
-    // model table: batched copy from a per-block replica (see wbc_quad_kernel)
-    const double* src = reinterpret_cast<const double*>(mp) + (size_t)(blockIdx.x % MODEL_REPLICAS) * MODEL_PAD_WORDS;
-    double t[MODEL_PAD_WORDS / BLOCK];
+  // Prologue: EVERY global load of the tick is issued here, unconditionally (clamped indices, no divergent
+  // guards), before the single wait: model table (per-block replica, see wbc_quad_kernel), the 91 x 4 input
+  // words, and the per-robot mask / mu / mass scale -- one memory round trip instead of two (profiles/r01/hex_cuts.md).
+  const double* msrc = reinterpret_cast<const double*>(mp) + (size_t)(blockIdx.x % MODEL_REPLICAS) * MODEL_PAD_WORDS;
+  double t[MODEL_PAD_WORDS / BLOCK], tmp[PER_LANE];
 #pragma unroll
-    for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) t[j] = src[j * BLOCK + threadIdx.x];
-    // inputs: 91 rows x 4 robots, 6 independent loads per lane
-    constexpr int PER_LANE = (NIN * HROBOTS + BLOCK - 1) / BLOCK;
-    double tmp[PER_LANE];
+  for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) t[j] = msrc[j * BLOCK + threadIdx.x];
+  {
     const int r0 = blockIdx.x * HROBOTS;
 #pragma unroll
     for (int j = 0; j < PER_LANE; j++) {
-      const int idx = j * BLOCK + threadIdx.x;
+      const int idx = min(j * BLOCK + (int)threadIdx.x, NIN * HROBOTS - 1);
       const int row = idx / HROBOTS, sl = idx % HROBOTS;
       const int rob = min(r0 + sl, n - 1);
       const double* srow = row < 19 ? q + (size_t)row * ld : (row < 37 ? v + (size_t)(row - 19) * ld : tg + (size_t)(row - 37) * ld);
-      tmp[j] = (idx < NIN * HROBOTS) ? srow[rob] : 0.0;
+      tmp[j] = srow[rob];
     }
-#pragma unroll
-    for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) mbuf[j * BLOCK + threadIdx.x] = t[j];
-#pragma unroll
-    for (int j = 0; j < PER_LANE; j++) {
-      const int idx = j * BLOCK + threadIdx.x;
-      if (idx < NIN * HROBOTS) inbuf[idx] = tmp[j];
-    }
-    __syncthreads();
   }
+  const unsigned mk = mask[ii] & 0xF;
+  const double mu_in = mu ? mu[ii] : 0.0, ms_in = ms ? ms[ii] : 1.0;
+#pragma unroll
+  for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) mbuf[j * BLOCK + threadIdx.x] = t[j];
+#pragma unroll
+  for (int j = 0; j < PER_LANE; j++) inbuf[j * BLOCK + threadIdx.x] = tmp[j];
+  __syncthreads();
   const wbc::ModelC& m = *reinterpret_cast<const wbc::ModelC*>(mbuf);
   const wbc::ParamsC& P = *pp;
   HexDev qo;
@@ -499,9 +498,8 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
     if (live && lead && met) met[(size_t)k * ld + ii] = x;
     if (k == 1) errv = x;
   };
-  const unsigned mk = mask[ii] & 0xF;
-  const double mui = mu ? mu[ii] : P.mu;
-  const double msi = ms ? ms[ii] : 1.0;
+  const double mui = mu ? mu_in : P.mu;
+  const double msi = ms_in;
   int iters = 0;
 #ifdef WBC_FORCE_SCRATCH   // diagnostic: give the kernel a private segment without changing its math
   volatile double junk[WBC_FORCE_SCRATCH];
