@@ -1,9 +1,11 @@
 // wbc_kernels.hip -- HIP kernels (gfx950) + the C ABI of include/wbc.h.
 //
-// Layout in HBM: struct-of-arrays, batch index fastest, so the 64 lanes of a wavefront read
-// 64 consecutive doubles of each input row (512 B, fully coalesced).  One lane = one robot:
-// the whole tick (FK -> CRBA/RNEA -> reduced QP assembly -> QR -> active set -> torques) is a
-// single fused launch, so the only HBM traffic is the 864 algorithmic bytes per tick.
+// Layout in HBM: struct-of-arrays, batch index fastest (row r of robot i at base[r*ld + i]).  The whole tick
+// (FK -> CRBA/RNEA -> reduced QP assembly -> QR -> active set -> torques) is ONE fused launch, so the only HBM
+// traffic is the 864 algorithmic bytes per tick.  Three mappings of a robot onto lanes, same math:
+//   wbc_hex_kernel   16 lanes (one DPP row) per robot, one QP column per lane       (wbc_hex.hpp; the default)
+//   wbc_quad_kernel   4 lanes per robot, lane = leg                                  (wbc_quad.hpp)
+//   wbc_tick_kernel   1 lane per robot; the only one with the optional torque box    (wbc_tick.hpp)
 //
 // There is no CPU path in this file: if HIP fails the entry points return an error.
 #include <hip/hip_runtime.h>
@@ -439,8 +441,11 @@ struct ParkLds {
   __device__ __forceinline__ double get(int i) const { return a[z + i]; }
 };
 
+#ifndef WBC_HEX_WAVES_PER_EU
+#define WBC_HEX_WAVES_PER_EU 1
+#endif
 template <int KIND>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WBC_HEX_WAVES_PER_EU)))
 wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld,
                const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
                const uint8_t* __restrict__ mask, const double* __restrict__ mu,
