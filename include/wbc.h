@@ -71,7 +71,7 @@ typedef struct {
 
 /* Gains, weights and friction: literals of the two ControlLaw bodies
  * (inverse_dynamics_controller.py:19,93,117-127; mptc_controller.py:20,115,143-153).
- * tau_max = +inf reproduces the reference (it has no torque rows);
+ * tau_max = +inf reproduces the reference (it has no torque rows); a finite value adds the box |tau_j| <= tau_max;
  * eps2 is the weight of the 1/2*eps2*|[tau; f]|^2 tie-break. */
 typedef struct {
   double Kp_body_p, Kd_body_p, Kp_body_rpy, Kd_body_rpy, Kp_foot, Kd_foot;
@@ -149,8 +149,8 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
 
 /* Kernel variant: 0 = auto (default), 1 = lane-per-robot, 2 = quad-per-robot (4 lanes = 4 legs),
  * 3 = 16 lanes (one DPP row) per robot.  All compute the same tick.  Auto: 16-lane for MPTC / PC / CLF at
- * any batch size and for ID up to n = 8192 (quad beyond); lane-per-robot when the optional torque box is
- * enabled.  The CLF law has no quad-per-robot kernel. */
+ * any batch size and for ID up to n = 8192 (quad beyond).  The CLF law and the optional torque box
+ * (tau_max < inf) have no quad-per-robot kernel. */
 int wbc_set_variant(wbc_handle h, int variant);
 /* The variant (1, 2 or 3) a wbc_step of n instances would run. */
 int wbc_variant_for(wbc_handle h, int n);

@@ -88,9 +88,14 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
 // Nothing lives in LDS and the loop has no divergent inner branches (profiles/r02/hex_cuts.md).
 // The optional dense row (index 16: the PC law's Vdot <= 0, the CLF law's CLF row) has its image / value /
 // multiplier replicated on all lanes.  NV = 13 for the CLF law (slack delta on lane HEX_DELTA_LANE).
-template <class Q, bool PC, int NV = NZ>
+// Optional torque box (TB): lane (leg, j < 3) also owns the two-sided row |tau_(leg,j)| <= tau_max of its own
+// joint in a second constraint slot (id 32 + lane): unit normal Tn of the torque-map row, normalised torque
+// yt = Tn.z + t0n tracked like s_h, bound bt = tau_max / |T_row| (< 0: slot not eligible).  Only one side of a
+// pair can be violated or active at a time; the side is a sign (sig) applied to the slot's image.
+template <class Q, bool PC, int NV = NZ, bool TB = false>
 WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, double inv_s, int* iters_out,
-                  double vrow_own = 0.0, double vc = 0.0, double pc_inv = 0.0) {
+                  double vrow_own = 0.0, double vc = 0.0, double pc_inv = 0.0, const double* Tn = nullptr,
+                  double t0n = 0.0, double bt = -1.0) {
   const int sb = h & 3;
   const bool pc = PC && pc_inv > 0.0;
   const double sg = (sb & 1) ? inv_s : -inv_s;   // own row: n_h = sg * e_(leg, sb>>1) + mu_n * e_(leg, 2)
@@ -113,12 +118,29 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   int pos_h = -1;
 #pragma unroll
   for (int k = 0; k < NV; k++) { Wr[k] = 0.0; Wpc[k] = 0.0; }
+  double Dt[NV], Wt[NV], yt = 0.0, dnt = 0.0, u_t = 0.0, sig_t = 1.0;
+  int pos_t = -1;
+  const bool elig_t = TB && bt >= 0.0;
+  if (TB) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) { Dt[k] = 0.0; Wt[k] = 0.0; }
+    yt = t0n;
+#pragma unroll
+    for (int c = 0; c < NZ; c++) {
+      const int src = hex_lane(c);
+#pragma unroll
+      for (int k = 0; k < NV; k++) Dt[k] += qo.bcast16(Jr[k], src) * Tn[c];
+      yt += qo.bcast16(z, src) * Tn[c];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) dnt += Dt[k] * Dt[k];
+  }
   int q = 0, iters = 0, status = ST_OK;
-  unsigned active = 0u;
+  unsigned long long active = 0ull;
   const int maxit = 200;
   bool done = false, need_pick = true;
   int p = -1;
-  double sp = 0.0, up = 0.0, dnp = 1.0;
+  double sp = 0.0, up = 0.0, dnp = 1.0, sgp = 1.0;
   const double INF = __builtin_huge_val();
   // feasibility tolerance from the scale of the unconstrained minimiser (the iterates stay on that scale)
   const double tol = 1e-13 * (1.0 + qo.max16(fabs(z)));
@@ -127,16 +149,21 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       // most violated inactive row: argmin of the tracked values
       sp = INF;
       p = -1;
-      if (ct && !((active >> h) & 1u)) { sp = sh_; p = h; }
+      if (ct && !((active >> h) & 1ull)) { sp = sh_; p = h; }
+      if (TB) {
+        const double st_ = bt - fabs(yt);
+        if (elig_t && !((active >> (32 + h)) & 1ull) && st_ < sp) { sp = st_; p = 32 + h; }
+      }
       qo.argmin16(sp, p);
-      if (pc && !((active >> 16) & 1u) && spc < sp) { sp = spc; p = 16; }
+      if (pc && !((active >> 16) & 1ull) && spc < sp) { sp = spc; p = 16; }
       if (!(sp < -tol)) p = -1;
       if (p < 0) {
         done = true;
       } else {
         up = 0.0;
-        dnp = qo.bcast16d(dnh, p & 15);
+        dnp = qo.bcast16d((TB && p >= 32) ? dnt : dnh, p & 15);
         if (PC) dnp = (p == 16) ? dnpc : dnp;
+        if (TB) sgp = (p >= 32) ? qo.bcast16d((yt > 0.0) ? -1.0 : 1.0, p & 15) : 1.0;   // violated side of a torque row
         need_pick = false;
       }
     }
@@ -146,28 +173,31 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     double d[NV], dm[NV], d2n = 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-      d[k] = qo.bcast16d(Dh[k], p & 15);
+      d[k] = TB ? sgp * qo.bcast16d((p >= 32) ? Dt[k] : Dh[k], p & 15) : qo.bcast16d(Dh[k], p & 15);
       if (PC) d[k] = (p == 16) ? Dpc[k] : d[k];
       dm[k] = (k >= q) ? d[k] : 0.0;
       d2n += dm[k] * dm[k];
     }
-    double zd = 0.0, sd = 0.0, sdpc = 0.0;
+    double zd = 0.0, sd = 0.0, sdpc = 0.0, sdt = 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       zd += Jr[k] * dm[k];
       sd += Dh[k] * dm[k];
       if (PC) sdpc += Dpc[k] * dm[k];
+      if (TB) sdt += Dt[k] * dm[k];
     }
     // dual step direction r = R^-1 d[0:q]: every active row's lane holds its row of W = R^-1
-    double r_h = 0.0, r_pc = 0.0;
+    double r_h = 0.0, r_pc = 0.0, r_t = 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       const double d1 = d[k] - dm[k];
       r_h += Wr[k] * d1;
       if (PC) r_pc += Wpc[k] * d1;
+      if (TB) r_t += Wt[k] * d1;
     }
     r_h = (pos_h >= 0) ? r_h : 0.0;
     if (PC) r_pc = (pos_pc >= 0) ? r_pc : 0.0;
+    if (TB) r_t = (pos_t >= 0) ? r_t : 0.0;
     // blocking multiplier: min over active rows with r > 0 of u / r (nothing to do while no row is active
     // anywhere in the wavefront -- every robot's first trip)
     double t1 = INF;
@@ -175,6 +205,10 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     if (qo.wave_max_int(q) > 0) {
       t1 = (pos_h >= 0 && r_h > 0.0) ? u_h * fast_rcp(r_h) : INF;
       hd = (t1 < INF) ? h : -1;
+      if (TB) {
+        const double c = (pos_t >= 0 && r_t > 0.0) ? u_t * fast_rcp(r_t) : INF;
+        if (c < t1) { t1 = c; hd = 32 + h; }
+      }
       qo.argmin16(t1, hd);
       if (PC) {
         const double c = (pos_pc >= 0 && r_pc > 0.0) ? u_pc * fast_rcp(r_pc) : INF;
@@ -189,12 +223,14 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     const double t = full ? t2 : t1;
     u_h -= t * r_h;
     if (PC) u_pc -= t * r_pc;
+    if (TB) u_t -= t * r_t;
     up += t;
     {
       const double tz = dependent ? 0.0 : t;
       z += tz * zd;
       sh_ += tz * sd;
       if (PC) spc += tz * sdpc;
+      if (TB) yt += tz * sdt;
       sp += tz * d2n;
     }
     if (full) {
@@ -207,7 +243,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       const double vq = dq - alpha;
       const double ia = fast_rcp(alpha);
       const double beta = fast_rcp(nrm * (nrm + fabs(dq)));   // 2 / (v'v)
-      double w = 0.0, wd = 0.0, wp = 0.0;
+      double w = 0.0, wd = 0.0, wp = 0.0, wt = 0.0;
       double hv[NV];
 #pragma unroll
       for (int k = 0; k < NV; k++) {
@@ -215,13 +251,15 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         w += Jr[k] * hv[k];
         wd += Dh[k] * hv[k];
         if (PC) wp += Dpc[k] * hv[k];
+        if (TB) wt += Dt[k] * hv[k];
       }
-      w *= beta; wd *= beta; wp *= beta;
+      w *= beta; wd *= beta; wp *= beta; wt *= beta;
 #pragma unroll
       for (int k = 0; k < NV; k++) {
         Jr[k] -= w * hv[k];
         Dh[k] -= wd * hv[k];
         if (PC) Dpc[k] -= wp * hv[k];
+        if (TB) Dt[k] -= wt * hv[k];
       }
       // W' = [W, -r/alpha; 0, 1/alpha]  (rows of inactive lanes are zero, r_h = 0 there)
       const bool mine = (h == p);
@@ -232,6 +270,13 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       }
       u_h = mine ? up : u_h;
       pos_h = mine ? q : pos_h;
+      if (TB) {
+        const bool tm = (p == 32 + h);
+        const double wq = tm ? ia : -r_t * ia;
+#pragma unroll
+        for (int k = 0; k < NV; k++) Wt[k] = (k == q) ? wq : Wt[k];
+        u_t = tm ? up : u_t; pos_t = tm ? q : pos_t; sig_t = tm ? sgp : sig_t;
+      }
       if (PC) {
         const bool pm = (p == 16);
         const double wq = pm ? ia : -r_pc * ia;
@@ -239,22 +284,29 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         for (int k = 0; k < NV; k++) Wpc[k] = (k == q) ? wq : Wpc[k];
         u_pc = pm ? up : u_pc; pos_pc = pm ? q : pos_pc;
       }
-      active |= (1u << p);
+      active |= (1ull << p);
       q++;
       need_pick = true;
       continue;
     }
     // partial / pure dual step: drop the active row hd (list position ld)
     {
-      int ld = qo.bcast16d_i(pos_h, hd & 15);
+      int ld = qo.bcast16d_i((TB && hd >= 32) ? pos_t : pos_h, hd & 15);
       if (PC) ld = (hd == 16) ? pos_pc : ld;
-      active &= ~(1u << hd);
+      active &= ~(1ull << hd);
       {
         const bool mine = (h == hd);
         u_h = mine ? 0.0 : u_h;
         pos_h = mine ? -1 : ((pos_h > ld) ? pos_h - 1 : pos_h);
 #pragma unroll
         for (int k = 0; k < NV; k++) Wr[k] = mine ? 0.0 : Wr[k];
+      }
+      if (TB) {
+        const bool tm = (hd == 32 + h);
+        u_t = tm ? 0.0 : u_t;
+        pos_t = tm ? -1 : ((pos_t > ld) ? pos_t - 1 : pos_t);
+#pragma unroll
+        for (int k = 0; k < NV; k++) Wt[k] = tm ? 0.0 : Wt[k];
       }
       if (PC) {
         const bool pm = (hd == 16);
@@ -269,8 +321,9 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       for (int j = 0; j < NV - 1; j++) {
         if (j >= ld && j < q) {
           // (a, b) = entries (j, j+1) of the column now at position j: the image of the row whose position is j
-          const bool here = (pos_h == j);
-          double a = qo.sum16(here ? Dh[j] : 0.0), b = qo.sum16(here ? Dh[j + 1] : 0.0);
+          const bool here = (pos_h == j), here_t = TB && (pos_t == j);
+          double a = qo.sum16(here ? Dh[j] : (here_t ? sig_t * Dt[j] : 0.0)),
+                 b = qo.sum16(here ? Dh[j + 1] : (here_t ? sig_t * Dt[j + 1] : 0.0));
           if (PC) { a = (pos_pc == j) ? Dpc[j] : a; b = (pos_pc == j) ? Dpc[j + 1] : b; }
           const double ih = fast_rcp(fast_sqrt(a * a + b * b));
           const double c = a * ih, sn = b * ih;
@@ -283,6 +336,10 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
             const double x = Wpc[j], y = Wpc[j + 1];
             Wpc[j] = c * x + sn * y;
             Wpc[j + 1] = c * y - sn * x;
+          }
+          if (TB) {
+            { const double x = Wt[j], y = Wt[j + 1]; Wt[j] = c * x + sn * y; Wt[j + 1] = c * y - sn * x; }
+            { const double x = Dt[j], y = Dt[j + 1]; Dt[j] = c * x + sn * y; Dt[j + 1] = c * y - sn * x; }
           }
           {
             const double x = Jr[j], y = Jr[j + 1];
@@ -374,7 +431,7 @@ WBC_HD double pick3(int sb, double a, double b, double c) { return (sb == 0) ? a
 
 // The tick.  Every lane of the row calls this with its own Q (lane id h = 4*leg + sub).
 // out_tau(row, x): lane (leg, j<3) writes the torque of joint 3*leg+j;  out_met: see the kernel.
-template <class Q, int KIND, class Park, class In, class OutTau, class OutMet>
+template <class Q, int KIND, bool TB, class Park, class In, class OutTau, class OutMet>
 WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned mask, double mu, double mass_scale,
                     Park& pk, OutTau out_tau, OutMet out_met, int* iters_out) {
   const int h = qo.lane();
@@ -897,20 +954,42 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     z = zacc;
   }
   WBC_HCUT_AT(6, z + Jr[0] + Jr[5] + Jr[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
-  // ---------------- friction rows
+  // ---------------- friction rows (+ the optional torque box)
   int iters = 0;
   {
     const double s = sqrt(1.0 + mu * mu);
+    // torque box: own row of the torque map tau = T z + t0' (t0' = t0_own + Y_row.ab0), normalised
+    double Tn[NZ], t0n = 0.0, bt = -1.0;
+    if (TB) {
+      double n2 = 0.0;
+#pragma unroll
+      for (int c = 0; c < NZ; c++) {
+        const int src = hex_lane(c);
+        double tc = (c / 3 == l) ? Drow[c % 3] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) tc += Yrow[k] * qo.bcast16(bcol[k], src);
+        Tn[c] = tc;
+        n2 += tc * tc;
+      }
+      double t0p = t0_own;
+#pragma unroll
+      for (int k = 0; k < 6; k++) t0p += Yrow[k] * ab0[k];
+      const double inrm = (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0;
+#pragma unroll
+      for (int c = 0; c < NZ; c++) Tn[c] *= inrm;
+      t0n = t0p * inrm;
+      bt = (colv && n2 > 0.0) ? P.tau_max * inrm : -1.0;
+    }
     int st;
     if (KIND == KIND_PC) {
       const double vr = colv ? vrow_own : 0.0;
       const double n2 = qo.sum16(vr * vr);
-      st = hex_gi<Q, true>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, vr, vconst + met_Vdot, (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0);
+      st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, vr, vconst + met_Vdot, (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0, Tn, t0n, bt);
     } else if (KIND == KIND_CLF) {
       // the CLF row  g . [z; delta] - ub <= 0  is the dense row of the active set (index 16), like PC's Vdot row
-      st = hex_gi<Q, true, NV>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, clf_g, -clf_ub, clf_inv);
+      st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt);
     } else {
-      st = hex_gi<Q, false>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters);
+      st = hex_gi<Q, false, NV, TB>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt);
     }
     if (st != ST_OK) status = st;
   }

@@ -5,7 +5,7 @@
 // traffic is the 864 algorithmic bytes per tick.  Three mappings of a robot onto lanes, same math:
 //   wbc_hex_kernel   16 lanes (one DPP row) per robot, one QP column per lane       (wbc_hex.hpp; the default)
 //   wbc_quad_kernel   4 lanes per robot, lane = leg                                  (wbc_quad.hpp)
-//   wbc_tick_kernel   1 lane per robot; the only one with the optional torque box    (wbc_tick.hpp)
+//   wbc_tick_kernel   1 lane per robot (the first version; A/B reference)            (wbc_tick.hpp)
 //
 // There is no CPU path in this file: if HIP fails the entry points return an error.
 #include <hip/hip_runtime.h>
@@ -444,7 +444,7 @@ struct ParkLds {
 #ifndef WBC_HEX_WAVES_PER_EU
 #define WBC_HEX_WAVES_PER_EU 1
 #endif
-template <int KIND>
+template <int KIND, bool TB = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WBC_HEX_WAVES_PER_EU)))
 wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld,
                const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
@@ -511,7 +511,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   for (int k = 0; k < WBC_FORCE_SCRATCH; k++) junk[k] = inbuf[k];
 #endif
   ParkLds park(parkbuf + slot * wbc::PK_N);
-  const int st = wbc::hex_tick<HexDev, KIND>(m, P, qo, in, mk, mui, msi, park, ot, om, &iters);
+  const int st = wbc::hex_tick<HexDev, KIND, TB>(m, P, qo, in, mk, mui, msi, park, ot, om, &iters);
 #ifdef WBC_FORCE_SCRATCH
   if (junk[threadIdx.x % WBC_FORCE_SCRATCH] == 1.2345e300) iters++;
 #endif
@@ -641,7 +641,7 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
   h->kind = kind; h->max_batch = max_batch; h->device = device; h->flags = flags;
   h->variant = 0;
   h->torque_box = P.tau_max < 1e300;
-  h->lane_only = h->torque_box;   // the optional torque box exists on the lane-per-robot kernel only
+  h->lane_only = false;           // every law and the optional torque box run on the 16-lane kernel
   HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   h->own_stream = true;
   HIP_TRY(hipMalloc(&h->d_model, (size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8));
@@ -703,7 +703,7 @@ int wbc_set_stream(wbc_handle h, void* hip_stream) {
 static int pick_variant(const wbc_handle_s* h, int n) {
   if (h->variant) return h->variant;
   if (h->lane_only) return 1;
-  if (h->kind != WBC_KIND_ID) return 3;   // MPTC, PC, CLF (CLF: 16-lane or lane-per-robot only)
+  if (h->kind != WBC_KIND_ID || h->torque_box) return 3;   // MPTC, PC, CLF, torque box: 16-lane (or lane-per-robot) only
   return (n + 3) / 4 <= 2048 ? 3 : 2;
 }
 
@@ -738,8 +738,20 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
                      mask, mu, ms, tau, met, status, d_stats, h->d_vdot)
   if (hex) {
     dim3 grid((n + HROBOTS - 1) / HROBOTS);
-    if (h->kind == WBC_KIND_CLF) WBC_LAUNCH_CLF(wbc_hex_kernel, grid);
-    else WBC_LAUNCH(wbc_hex_kernel, grid);
+#define WBC_HEX_ARGS grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg, mask, mu, ms, tau, met, status, d_stats, h->d_vdot
+    if (h->torque_box) {   // second constraint slot per lane: |tau_j| <= tau_max (wbc_hex.hpp)
+      switch (h->kind) {
+        case WBC_KIND_ID: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_ID, true>), WBC_HEX_ARGS); break;
+        case WBC_KIND_MPTC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_MPTC, true>), WBC_HEX_ARGS); break;
+        case WBC_KIND_PC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_PC, true>), WBC_HEX_ARGS); break;
+        default: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_CLF, true>), WBC_HEX_ARGS);
+      }
+    } else if (h->kind == WBC_KIND_CLF) {
+      WBC_LAUNCH_CLF(wbc_hex_kernel, grid);
+    } else {
+      WBC_LAUNCH(wbc_hex_kernel, grid);
+    }
+#undef WBC_HEX_ARGS
   } else if (quad) {
     dim3 grid((n + QROBOTS - 1) / QROBOTS);
     WBC_LAUNCH(wbc_quad_kernel, grid);
@@ -898,8 +910,8 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
 int wbc_set_variant(wbc_handle h, int variant) {
   if (!h) return misuse("wbc_set_variant: null handle");
   if (variant < 0 || variant > 3) return misuse("wbc_set_variant: 0 = auto, 1 = lane-per-robot, 2 = quad-per-robot, 3 = 16 lanes per robot");
-  if (variant >= 2 && h->lane_only) return misuse("wbc_set_variant: the torque box exists on the lane-per-robot kernel only");
-  if (variant == 2 && h->kind == WBC_KIND_CLF) return misuse("wbc_set_variant: the CLF law runs on the 16-lane or the lane-per-robot kernel");
+  if (variant == 2 && (h->kind == WBC_KIND_CLF || h->torque_box))
+    return misuse("wbc_set_variant: the CLF law and the torque box run on the 16-lane or the lane-per-robot kernel");
   h->variant = variant;
   return 0;
 }
@@ -915,7 +927,11 @@ int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_by
   const int var = h->last_variant ? h->last_variant : pick_variant(h, h->max_batch);
   const bool quad = (var == 2);
   const void* fn;
-  if (var == 3) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID>
+  if (var == 3 && h->torque_box)
+    fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID, true>
+       : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_kernel<wbc::KIND_MPTC, true>
+       : h->kind == WBC_KIND_PC ? (const void*)wbc_hex_kernel<wbc::KIND_PC, true> : (const void*)wbc_hex_kernel<wbc::KIND_CLF, true>;
+  else if (var == 3) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID>
                : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_kernel<wbc::KIND_MPTC>
                : h->kind == WBC_KIND_PC ? (const void*)wbc_hex_kernel<wbc::KIND_PC> : (const void*)wbc_hex_kernel<wbc::KIND_CLF>;
   else if (quad) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_quad_kernel<wbc::KIND_ID>

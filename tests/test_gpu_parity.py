@@ -136,6 +136,24 @@ def test_torque_box_friction_and_host_pointer_mode():
     assert rel_err(tau[:, ok], tau_o[:, ok]).max() < TOL
 
 
+@pytest.mark.parametrize("variant", ["hex", "lane"])
+@pytest.mark.parametrize("cfg,kind,tmax", [(3, "mptc", 10.0), (2, "id", 12.0), (3, "clf", 12.0), (3, "pc", 10.0)])
+def test_torque_box_on_both_mappings(cfg, kind, tmax, variant):
+    """tau_max < inf: 24 more inequality rows (north star: torque-limit inequalities); device pointers, N = 512."""
+    from oracle import oracle_py as orc
+    from quadruped_drake_amd import workloads
+    b = workloads.make_batch(cfg, n=512)
+    tau, met, st, stats = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"],
+                                   params={"tau_max": tmax}, variant=variant)
+    p = orc.params(kind); p.tau_max = tmax
+    tau_o, _, st_o = orc.step_batch(kind, orc.model(b["model"]), p, b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
+    assert np.array_equal(st == 0, st_o == 0)
+    ok = st == 0
+    assert ok.sum() > 400 and np.abs(tau[:, ok]).max() <= tmax + 1e-9
+    assert (np.abs(np.abs(tau[:, ok]) - tmax) < 1e-6).sum() > 100
+    assert rel_err(tau[:, ok], tau_o[:, ok]).max() < TOL
+
+
 def test_joint_and_actuator_permutations():
     from quadruped_drake_amd import workloads
     b = workloads.make_batch(3, n=64)

@@ -126,6 +126,29 @@ def test_hex_all_contact_masks_on_host():
         assert np.allclose(met, met_o, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("cfg,kind,tmax,mu", [(2, "id", 12.0, 0.45), (3, "mptc", 10.0, 0.7), (3, "id", 8.0, 0.7), (3, "pc", 10.0, 0.7),
+                                              (3, "clf", 12.0, 0.7), (4, "mptc", 25.0, 0.7), (3, "mptc", 2.0, 0.7)])
+def test_hex_torque_box(cfg, kind, tmax, mu):
+    """Optional torque box |tau_j| <= tau_max on the 16-lane mapping (second constraint slot per lane): same
+    torques as the literal oracle QP with its 24 torque rows, same feasibility verdicts (a 2 N.m box is infeasible
+    for some states), torques clamp at the bound, and the lane-per-robot mapping agrees."""
+    b = workloads.make_batch(cfg, n=32)
+    t = orc.load_model_json(b["model"]); m = orc.model(b["model"])
+    p = orc.params(kind); p.tau_max = tmax; p.mu = mu
+    tau_o, _, st_o = orc.step_batch(kind, m, p, b["q"], b["v"], b["targets"], b["mask"])
+    pp = np.array([p.Kp_body_p, p.Kd_body_p, p.Kp_body_rpy, p.Kd_body_rpy, p.Kp_foot, p.Kd_foot, p.w_body,
+                   p.w_foot, p.mu, p.Kd_contact, p.tau_max, p.tiebreak_eps2])
+    tl, _, sl, _ = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], params12=pp)
+    th, _, sh, _ = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], params12=pp, hexv=True)
+    assert np.array_equal(sh == 0, st_o == 0) and np.array_equal(sh, sl)
+    ok = sh == 0
+    assert ok.sum() >= 24
+    assert np.abs(th[:, ok]).max() <= tmax + 1e-9
+    assert (np.abs(np.abs(th[:, ok]) - tmax) < 1e-6).sum() >= 20          # the box is active on this batch
+    assert rel_err(th[:, ok], tau_o[:, ok]).max() < 1e-5
+    assert rel_err(th[:, ok], tl[:, ok]).max() < 1e-5
+
+
 def test_straight_knee_is_reported_not_solved():
     """Known limit of the reduced (task-coordinate) formulation: it inverts every leg's 3x3 foot Jacobian, so a
     fully straight knee (kinematic singularity) is reported as status 2 with zero torques by all three kernel
