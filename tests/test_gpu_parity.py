@@ -241,6 +241,25 @@ def test_three_kernel_mappings_agree_at_full_size(kind, cfg):
         assert (out["hex"][1][3] <= 1e-7).all() and (out["quad"][1][3] <= 1e-7).all()
 
 
+@pytest.mark.parametrize("cfg,kind,n", [(5, "mptc", 32768), (3, "mptc", 4096), (2, "id", 4096), (4, "mptc", 4096), (3, "pc", 4096), (3, "clf", 4096)])
+def test_full_size_oracle_parity(cfg, kind, n):
+    """Every instance of the BASELINE full-size batches against the oracle (all host threads: a few seconds on
+    the GPU box; the oracle is the checker, never the thing measured)."""
+    from oracle import oracle_py as orc
+    from quadruped_drake_amd import workloads
+    b = workloads.make_batch(cfg, n=n)
+    tau, met, st, stats = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
+    cores = len(os.sched_getaffinity(0))
+    tau_o, met_o, st_o = orc.step_batch(kind, orc.model(b["model"]), orc.params(kind), b["q"], b["v"], b["targets"], b["mask"],
+                                        b["mu"], b["mass_scale"], nthreads=cores)
+    assert (st == 0).all() and (st_o == 0).all()
+    r = rel_err(tau, tau_o)
+    assert r.max() < TOL, (r.max(), int(r.argmax()))
+    assert np.median(r) < 1e-9
+    assert np.allclose(met, met_o, rtol=1e-5, atol=1e-6)
+    assert stats["ticks"] == n
+
+
 def test_sub_batch_with_leading_dimension():
     """ld > n: a shard of a larger SoA array is stepped in place (what a multi-GPU shard does)."""
     torch = _torch()
