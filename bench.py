@@ -102,6 +102,7 @@ def main():
 
     for _ in range(a.warmup):
         ctrl.step(q, v, tg, mask, mu, ms, out=out)
+    wstats.all_reduce_stats(ctrl.stats(), device=dev)            # warm the statistics exchange (RCCL channel set-up) as well
     ctrl.stats(reset=True)
     torch.cuda.synchronize()
     if world > 1:

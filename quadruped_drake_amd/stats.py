@@ -2,7 +2,7 @@
 
 The robot-instance batch shards embarrassingly: rank g owns instances [g*N/W, (g+1)*N/W) and no
 instance reads another's state, so there is no data-path collective.  The only exchange is one
-all-reduce of a ~22-double statistics vector at the end of a rollout (SUM fields and one MAX field)
+all-gather of a 22-double statistics vector at the end of a rollout (reduced locally: SUM fields and one MAX field)
 -- RCCL over xGMI on the GPU box (backend "nccl"), gloo in the CPU tests.  At < 200 B the message
 is latency-bound; link bandwidth is irrelevant.
 """
@@ -50,8 +50,9 @@ def all_reduce_stats(stats, device=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return dict(stats)
     s, m = pack(stats)
-    ts = torch.tensor(s, dtype=torch.float64, device=device)
-    tm = torch.tensor(m, dtype=torch.float64, device=device)
-    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-    return unpack(ts.cpu().numpy(), tm.cpu().numpy())
+    # ONE collective: gather every rank's 22-double vector, reduce (sum / max) locally
+    t = torch.tensor(np.concatenate([s, m]), dtype=torch.float64, device=device)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    a = torch.stack(parts).cpu().numpy()
+    return unpack(a[:, :len(s)].sum(0), a[:, len(s):].max(0))
