@@ -427,7 +427,11 @@ struct HexDev {
   }
 };
 
-constexpr int HROBOTS = BLOCK / 16;  // robots per 64-lane block
+#ifndef WBC_HEX_BLOCK
+#define WBC_HEX_BLOCK 64
+#endif
+constexpr int HEX_BLOCK = WBC_HEX_BLOCK;   // threads per workgroup of the 16-lane kernel (64 or 256)
+constexpr int HROBOTS = HEX_BLOCK / 16;    // robots per workgroup
 // robot-level park in LDS (wbc_hex.hpp): reads go through a laundered pointer so that the compiler
 // cannot forward the stored values (i.e. keep them in registers / spill them) yet the loads stay
 // ordinary, schedulable LDS loads
@@ -445,15 +449,16 @@ struct ParkLds {
 #define WBC_HEX_WAVES_PER_EU 1
 #endif
 template <int KIND, bool TB = false>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WBC_HEX_WAVES_PER_EU)))
+__global__ void __launch_bounds__(HEX_BLOCK) __attribute__((amdgpu_waves_per_eu(WBC_HEX_WAVES_PER_EU)))
 wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld,
                const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
                const uint8_t* __restrict__ mask, const double* __restrict__ mu,
                const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
                int32_t* __restrict__ status, StatsDev* __restrict__ stats, double* __restrict__ vdot) {
-  constexpr int PER_LANE = (NIN * HROBOTS + BLOCK - 1) / BLOCK;   // 6 input words per lane
-  __shared__ double mbuf[MODEL_PAD_WORDS];
-  __shared__ double inbuf[PER_LANE * BLOCK];                      // 91 rows x 4 robots, padded to whole lanes
+  constexpr int PER_LANE = (NIN * HROBOTS + HEX_BLOCK - 1) / HEX_BLOCK;   // 6 input words per lane
+  constexpr int MPER = (MODEL_PAD_WORDS + HEX_BLOCK - 1) / HEX_BLOCK;
+  __shared__ double mbuf[MPER * HEX_BLOCK];
+  __shared__ double inbuf[PER_LANE * HEX_BLOCK];                      // 91 rows x 4 robots, padded to whole lanes
   __shared__ double parkbuf[HROBOTS * wbc::PK_N];
   const int slot = threadIdx.x >> 4;
   const int i = blockIdx.x * HROBOTS + slot;
@@ -463,14 +468,14 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   // guards), before the single wait: model table (per-block replica, see wbc_quad_kernel), the 91 x 4 input
   // words, and the per-robot mask / mu / mass scale -- one memory round trip instead of two (profiles/r01/hex_cuts.md).
   const double* msrc = reinterpret_cast<const double*>(mp) + (size_t)(blockIdx.x % MODEL_REPLICAS) * MODEL_PAD_WORDS;
-  double t[MODEL_PAD_WORDS / BLOCK], tmp[PER_LANE];
+  double t[MPER], tmp[PER_LANE];
 #pragma unroll
-  for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) t[j] = msrc[j * BLOCK + threadIdx.x];
+  for (int j = 0; j < MPER; j++) t[j] = msrc[min(j * HEX_BLOCK + (int)threadIdx.x, MODEL_PAD_WORDS - 1)];
   {
     const int r0 = blockIdx.x * HROBOTS;
 #pragma unroll
     for (int j = 0; j < PER_LANE; j++) {
-      const int idx = min(j * BLOCK + (int)threadIdx.x, NIN * HROBOTS - 1);
+      const int idx = min(j * HEX_BLOCK + (int)threadIdx.x, NIN * HROBOTS - 1);
       const int row = idx / HROBOTS, sl = idx % HROBOTS;
       const int rob = min(r0 + sl, n - 1);
       const double* srow = row < 19 ? q + (size_t)row * ld : (row < 37 ? v + (size_t)(row - 19) * ld : tg + (size_t)(row - 37) * ld);
@@ -480,9 +485,9 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   const unsigned mk = mask[ii] & 0xF;
   const double mu_in = mu ? mu[ii] : 0.0, ms_in = ms ? ms[ii] : 1.0;
 #pragma unroll
-  for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) mbuf[j * BLOCK + threadIdx.x] = t[j];
+  for (int j = 0; j < MPER; j++) mbuf[j * HEX_BLOCK + threadIdx.x] = t[j];
 #pragma unroll
-  for (int j = 0; j < PER_LANE; j++) inbuf[j * BLOCK + threadIdx.x] = tmp[j];
+  for (int j = 0; j < PER_LANE; j++) inbuf[j * HEX_BLOCK + threadIdx.x] = tmp[j];
   __syncthreads();
   const wbc::ModelC& m = *reinterpret_cast<const wbc::ModelC*>(mbuf);
   const wbc::ParamsC& P = *pp;
@@ -738,7 +743,7 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
                      mask, mu, ms, tau, met, status, d_stats, h->d_vdot)
   if (hex) {
     dim3 grid((n + HROBOTS - 1) / HROBOTS);
-#define WBC_HEX_ARGS grid, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg, mask, mu, ms, tau, met, status, d_stats, h->d_vdot
+#define WBC_HEX_ARGS grid, dim3(HEX_BLOCK), 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg, mask, mu, ms, tau, met, status, d_stats, h->d_vdot
     if (h->torque_box) {   // second constraint slot per lane: |tau_j| <= tau_max (wbc_hex.hpp)
       switch (h->kind) {
         case WBC_KIND_ID: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_ID, true>), WBC_HEX_ARGS); break;
@@ -746,10 +751,13 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
         case WBC_KIND_PC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_PC, true>), WBC_HEX_ARGS); break;
         default: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_CLF, true>), WBC_HEX_ARGS);
       }
-    } else if (h->kind == WBC_KIND_CLF) {
-      WBC_LAUNCH_CLF(wbc_hex_kernel, grid);
     } else {
-      WBC_LAUNCH(wbc_hex_kernel, grid);
+      switch (h->kind) {
+        case WBC_KIND_ID: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_ID, false>), WBC_HEX_ARGS); break;
+        case WBC_KIND_MPTC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_MPTC, false>), WBC_HEX_ARGS); break;
+        case WBC_KIND_PC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_PC, false>), WBC_HEX_ARGS); break;
+        default: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_CLF, false>), WBC_HEX_ARGS);
+      }
     }
 #undef WBC_HEX_ARGS
   } else if (quad) {
@@ -943,7 +951,7 @@ int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_by
   if (num_vgpr) *num_vgpr = a.numRegs;
   if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;
   if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;
-  if (block_threads) *block_threads = BLOCK;
+  if (block_threads) *block_threads = (var == 3) ? HEX_BLOCK : BLOCK;
   return 0;
 }
 
