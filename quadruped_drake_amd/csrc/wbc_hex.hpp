@@ -70,6 +70,24 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
   }
 }
 
+// 16-lane argmin as ONE fmin butterfly: the 5-bit candidate index rides in the low mantissa bits of the value
+// (a 2^-47 relative perturbation of the returned minimum; "no candidate" is the finite HEX_NONE, never inf, so
+// that the packed key is never a NaN).  4 x (2 DPP moves + v_min_f64) instead of 4 x ~12 compare/select steps.
+constexpr double HEX_NONE = 1e300;
+WBC_HD double hex_pack_key(double v, int idx) {
+  unsigned long long b;
+  __builtin_memcpy(&b, &v, 8);
+  b = (b & ~0x1Full) | (unsigned long long)(idx & 31);
+  double k;
+  __builtin_memcpy(&k, &b, 8);
+  return k;
+}
+WBC_HD int hex_key_index(double k) {
+  unsigned long long b;
+  __builtin_memcpy(&b, &k, 8);
+  return (int)(b & 31ull);
+}
+
 // Goldfarb-Idnani on the friction rows, register-resident "constraint-space" form.
 //
 // Friction row h = 4*leg + r lives on lane h.  Besides its row Jr of J (J J' = H^-1) every lane carries
@@ -146,15 +164,20 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   const double tol = 1e-13 * (1.0 + qo.max16(fabs(z)));
   for (int trip = 0; trip < maxit; trip++) {
     if (!done && need_pick) {
-      // most violated inactive row: argmin of the tracked values
-      sp = INF;
-      p = -1;
-      if (ct && !((active >> h) & 1ull)) { sp = sh_; p = h; }
-      if (TB) {
-        const double st_ = bt - fabs(yt);
-        if (elig_t && !((active >> (32 + h)) & 1ull) && st_ < sp) { sp = st_; p = 32 + h; }
+      // most violated inactive row: argmin of the tracked values (friction slot: index h, torque slot: 16 + h)
+      {
+        double key = HEX_NONE;
+        if (ct && !((active >> h) & 1ull)) key = hex_pack_key(sh_, h);
+        if (TB) {
+          const double st_ = bt - fabs(yt);
+          if (elig_t && !((active >> (32 + h)) & 1ull) && st_ < key) key = hex_pack_key(st_, 16 + h);
+        }
+        key = qo.min16(key);
+        const int ix = hex_key_index(key);
+        sp = key;
+        p = (key < 1e299) ? ((ix < 16) ? ix : 16 + ix) : -1;   // torque slot ids are 32 + lane
+        if (p < 0) sp = INF;
       }
-      qo.argmin16(sp, p);
       if (pc && !((active >> 16) & 1ull) && spc < sp) { sp = spc; p = 16; }
       if (!(sp < -tol)) p = -1;
       if (p < 0) {
@@ -203,13 +226,16 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     double t1 = INF;
     int hd = -1;
     if (qo.wave_max_int(q) > 0) {
-      t1 = (pos_h >= 0 && r_h > 0.0) ? u_h * fast_rcp(r_h) : INF;
-      hd = (t1 < INF) ? h : -1;
+      double key = (pos_h >= 0 && r_h > 0.0) ? hex_pack_key(u_h * fast_rcp(r_h), h) : HEX_NONE;
       if (TB) {
-        const double c = (pos_t >= 0 && r_t > 0.0) ? u_t * fast_rcp(r_t) : INF;
-        if (c < t1) { t1 = c; hd = 32 + h; }
+        const double c = (pos_t >= 0 && r_t > 0.0) ? u_t * fast_rcp(r_t) : HEX_NONE;
+        if (c < key) key = hex_pack_key(c, 16 + h);
       }
-      qo.argmin16(t1, hd);
+      key = qo.min16(key);
+      const int ix = hex_key_index(key);
+      const bool any = key < 1e299;
+      t1 = any ? key : INF;
+      hd = any ? ((ix < 16) ? ix : 16 + ix) : -1;
       if (PC) {
         const double c = (pos_pc >= 0 && r_pc > 0.0) ? u_pc * fast_rcp(r_pc) : INF;
         if (c < t1) { t1 = c; hd = 16; }

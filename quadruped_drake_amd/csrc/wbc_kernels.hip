@@ -397,6 +397,13 @@ struct HexDev {
     return x;
   }
   __device__ __forceinline__ double sum16(double x) const { return legs_sum(leg_sum(x)); }
+  __device__ __forceinline__ double min16(double x) const {
+    x = fmin(x, dpp<0xB1>(x));
+    x = fmin(x, dpp<0x4E>(x));
+    x = fmin(x, dpp<0x128>(x));
+    x = fmin(x, dpp<0x124>(x));
+    return x;
+  }
   __device__ __forceinline__ double max16(double x) const {
     x = fmax(x, dpp<0xB1>(x));
     x = fmax(x, dpp<0x4E>(x));

@@ -295,6 +295,13 @@ struct HexHost {
     const double r = (quad_of(s, h) + quad_of(s, h ^ 8)) + (quad_of(s, h ^ 4) + quad_of(s, h ^ 12)); hex_barrier(h);
     return r;
   }
+  double min16(double x) {
+    g_hex->slot[h] = x; hex_barrier(h);
+    double r = g_hex->slot[0];
+    for (int k = 1; k < 16; k++) r = fmin(r, g_hex->slot[k]);
+    hex_barrier(h);
+    return r;
+  }
   double max16(double x) {
     g_hex->slot[h] = x; hex_barrier(h);
     double r = g_hex->slot[0];
