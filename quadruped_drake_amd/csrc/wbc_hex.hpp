@@ -155,6 +155,11 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   }
   int q = 0, iters = 0, status = ST_OK;
   unsigned long long active = 0ull;
+  // position masks kept as doubles (replicated): eq = one-hot of the next free position q, mk = 1 on the free
+  // positions k >= q.  Products with them replace three select chains per trip (d masked, d[q], the reflector).
+  double eq[NV], mk[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k++) { eq[k] = (k == 0) ? 1.0 : 0.0; mk[k] = 1.0; }
   const int maxit = 200;
   bool done = false, need_pick = true;
   int p = -1;
@@ -198,7 +203,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     for (int k = 0; k < NV; k++) {
       d[k] = TB ? sgp * qo.bcast16d((p >= 32) ? Dt[k] : Dh[k], p & 15) : qo.bcast16d(Dh[k], p & 15);
       if (PC) d[k] = (p == 16) ? Dpc[k] : d[k];
-      dm[k] = (k >= q) ? d[k] : 0.0;
+      dm[k] = d[k] * mk[k];
       d2n += dm[k] * dm[k];
     }
     double zd = 0.0, sd = 0.0, sdpc = 0.0, sdt = 0.0;
@@ -261,9 +266,10 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     }
     if (full) {
       // one Householder reflection H on d[q:] (H d2 = alpha e_q);  J2 <- J2 H on the own row, images alike
-      double dq = 0.0;
+      double dq = 0.0, dq1 = 0.0;
 #pragma unroll
-      for (int k = 0; k < NV; k++) dq = (k == q) ? d[k] : dq;
+      for (int k = 0; k < NV; k += 2) { dq += eq[k] * d[k]; if (k + 1 < NV) dq1 += eq[k + 1] * d[k + 1]; }
+      dq += dq1;
       const double nrm = fast_sqrt(d2n);
       const double alpha = (dq > 0.0) ? -nrm : nrm;
       const double vq = dq - alpha;
@@ -273,7 +279,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       double hv[NV];
 #pragma unroll
       for (int k = 0; k < NV; k++) {
-        hv[k] = (k == q) ? vq : dm[k];
+        hv[k] = dm[k] - alpha * eq[k];   // entry q: dq - alpha = vq
         w += Jr[k] * hv[k];
         wd += Dh[k] * hv[k];
         if (PC) wp += Dpc[k] * hv[k];
@@ -292,7 +298,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       {
         const double wq = mine ? ia : -r_h * ia;
 #pragma unroll
-        for (int k = 0; k < NV; k++) Wr[k] = (k == q) ? wq : Wr[k];
+        for (int k = 0; k < NV; k++) Wr[k] += eq[k] * wq;   // slot q is zero beforehand
       }
       u_h = mine ? up : u_h;
       pos_h = mine ? q : pos_h;
@@ -300,18 +306,23 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         const bool tm = (p == 32 + h);
         const double wq = tm ? ia : -r_t * ia;
 #pragma unroll
-        for (int k = 0; k < NV; k++) Wt[k] = (k == q) ? wq : Wt[k];
+        for (int k = 0; k < NV; k++) Wt[k] += eq[k] * wq;
         u_t = tm ? up : u_t; pos_t = tm ? q : pos_t; sig_t = tm ? sgp : sig_t;
       }
       if (PC) {
         const bool pm = (p == 16);
         const double wq = pm ? ia : -r_pc * ia;
 #pragma unroll
-        for (int k = 0; k < NV; k++) Wpc[k] = (k == q) ? wq : Wpc[k];
+        for (int k = 0; k < NV; k++) Wpc[k] += eq[k] * wq;
         u_pc = pm ? up : u_pc; pos_pc = pm ? q : pos_pc;
       }
       active |= (1ull << p);
       q++;
+#pragma unroll
+      for (int k = NV - 1; k >= 0; k--) {
+        mk[k] -= eq[k];
+        eq[k] = (k > 0) ? eq[k - 1] : 0.0;
+      }
       need_pick = true;
       continue;
     }
@@ -383,6 +394,15 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
             Dpc[j + 1] = c * y - sn * x;
           }
         }
+      }
+      // masks of the new size; the vacated slot q of every W row becomes zero again (appends add into it)
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        eq[k] = (k == q) ? 1.0 : 0.0;
+        mk[k] = (k >= q) ? 1.0 : 0.0;
+        Wr[k] -= eq[k] * Wr[k];
+        if (PC) Wpc[k] -= eq[k] * Wpc[k];
+        if (TB) Wt[k] -= eq[k] * Wt[k];
       }
     }
   }
