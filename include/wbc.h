@@ -149,7 +149,7 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
 
 /* Kernel variant: 0 = auto (default), 1 = lane-per-robot, 2 = quad-per-robot (4 lanes = 4 legs),
  * 3 = 16 lanes (one DPP row) per robot.  All compute the same tick.  Auto: 16-lane for MPTC / PC / CLF at
- * any batch size and for ID up to n = 8192 (quad beyond).  The CLF law and the optional torque box
+ * any batch size and for ID up to n = 16384 (quad beyond).  The CLF law and the optional torque box
  * (tau_max < inf) have no quad-per-robot kernel. */
 int wbc_set_variant(wbc_handle h, int variant);
 /* The variant (1, 2 or 3) a wbc_step of n instances would run. */

@@ -709,14 +709,14 @@ int wbc_set_stream(wbc_handle h, void* hip_stream) {
 }
 
 // variant 0 = auto.  Measured on MI355X (profiles/r01/hex_sweep.md): the 16-lane kernel wins at every batch
-// size for MPTC/PC; for the (active-set-bound) ID law it wins while its n/4 wavefronts fit two per SIMD of
-// the 256 CUs, beyond that the quad kernel's lower total instruction count wins.  The torque box and the CLF law exist on the
+// size for MPTC/PC; for the (active-set-bound) ID law it wins while its n/4 wavefronts fit four per SIMD of
+// the 256 CUs (N <= 16384), beyond that the quad kernel's lower total instruction count wins.  The torque box and the CLF law exist on the
 // lane-per-robot kernel only.
 static int pick_variant(const wbc_handle_s* h, int n) {
   if (h->variant) return h->variant;
   if (h->lane_only) return 1;
   if (h->kind != WBC_KIND_ID || h->torque_box) return 3;   // MPTC, PC, CLF, torque box: 16-lane (or lane-per-robot) only
-  return (n + 3) / 4 <= 2048 ? 3 : 2;
+  return (n + 3) / 4 <= 4096 ? 3 : 2;
 }
 
 static int launch(wbc_handle h, int n, int ld, const double* q, const double* v, const double* tg,
