@@ -970,14 +970,11 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       return x; }();
     const double inv_own = 1.0 / rown;
     double invd[NV];
-    double rmax = 0.0, rmin = 0.0;
 #pragma unroll
-    for (int c = 0; c < NV; c++) {
-      invd[c] = qo.bcast16(inv_own, hex_lane(c));
-      const double a = fabs(invd[c]);   // 1/|R_cc|: max <-> min swap
-      if (c == 0 || a > rmax) rmax = a;
-      if (c == 0 || a < rmin) rmin = a;
-    }
+    for (int c = 0; c < NV; c++) invd[c] = qo.bcast16(inv_own, hex_lane(c));
+    // pivot range over the column lanes (1/|R_cc|: max <-> min swap)
+    const double ainv = fabs(inv_own);
+    const double rmax = qo.max16((colv || cold) ? ainv : 0.0), rmin = qo.min16((colv || cold) ? ainv : HEX_NONE);
     // rmin/rmax here are of 1/|R_cc|:  min|R| / max|R| = rmin / rmax;  a zero pivot gives inf/nan -> singular
     if (!(rmin > 1e-13 * rmax) || !(rmax < 1e300)) status = ST_SINGULAR;
     if (status == ST_SINGULAR) {
