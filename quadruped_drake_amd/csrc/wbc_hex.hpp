@@ -215,13 +215,13 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       if (TB) sdt += Dt[k] * dm[k];
     }
     // dual step direction r = R^-1 d[0:q]: every active row's lane holds its row of W = R^-1
+    // (slots k >= q of every W row are zero by construction, so d needs no masking here)
     double r_h = 0.0, r_pc = 0.0, r_t = 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-      const double d1 = d[k] - dm[k];
-      r_h += Wr[k] * d1;
-      if (PC) r_pc += Wpc[k] * d1;
-      if (TB) r_t += Wt[k] * d1;
+      r_h += Wr[k] * d[k];
+      if (PC) r_pc += Wpc[k] * d[k];
+      if (TB) r_t += Wt[k] * d[k];
     }
     r_h = (pos_h >= 0) ? r_h : 0.0;
     if (PC) r_pc = (pos_pc >= 0) ? r_pc : 0.0;

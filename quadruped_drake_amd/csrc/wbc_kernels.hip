@@ -467,6 +467,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   __shared__ double mbuf[MPER * HEX_BLOCK];
   __shared__ double inbuf[PER_LANE * HEX_BLOCK];                      // 91 rows x 4 robots, padded to whole lanes
   __shared__ double parkbuf[HROBOTS * wbc::PK_N];
+  WBC_STAMP(0);
   const int slot = threadIdx.x >> 4;
   const int i = blockIdx.x * HROBOTS + slot;
   const bool live = i < n;
@@ -489,13 +490,16 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
       tmp[j] = srow[rob];
     }
   }
+  WBC_STAMP(1);   // all loads issued
   const unsigned mk = mask[ii] & 0xF;
   const double mu_in = mu ? mu[ii] : 0.0, ms_in = ms ? ms[ii] : 1.0;
 #pragma unroll
   for (int j = 0; j < MPER; j++) mbuf[j * HEX_BLOCK + threadIdx.x] = t[j];
 #pragma unroll
   for (int j = 0; j < PER_LANE; j++) inbuf[j * HEX_BLOCK + threadIdx.x] = tmp[j];
+  WBC_STAMP(2);   // LDS writes issued (loads landed)
   __syncthreads();
+  WBC_STAMP(3);
   const wbc::ModelC& m = *reinterpret_cast<const wbc::ModelC*>(mbuf);
   const wbc::ParamsC& P = *pp;
   HexDev qo;
@@ -527,6 +531,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
 #ifdef WBC_FORCE_SCRATCH
   if (junk[threadIdx.x % WBC_FORCE_SCRATCH] == 1.2345e300) iters++;
 #endif
+  WBC_STAMP(4);   // tick done
   if (live && lead && status) status[ii] = st;
   if (stats) {
     // per-robot reductions on the DPP row, then fire-and-forget atomics from the robot's lead lane into
@@ -543,6 +548,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
       atomicAdd(&stats->mask_count[mk], 1.0);
     }
   }
+  WBC_STAMP(5);
 }
 
 // ---------------------------------------------------------------- forward step
