@@ -20,5 +20,7 @@ t = buf[:, :6].astype(np.int64)
 d = np.diff(t, axis=1)
 names = ["kernarg + address setup + load issue", "mask/mu loads issued -> loads landed, LDS writes", "barrier", "tick", "stats tail"]
 for i, nm in enumerate(names): print("%-52s median %7d  p90 %7d cycles" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 90)))
+tot = t[:, 5] - t[:, 0]
+print("wave lifetime first->last stamp: p10 %d p50 %d p90 %d p99 %d max %d cycles" % tuple(np.percentile(tot, [10, 50, 90, 99, 100])))
 print("first stamp spread across blocks (launch skew): p10 %d p50 %d p90 %d max %d cycles" % tuple(np.percentile(t[:, 0] - t[:, 0].min(), [10, 50, 90, 100])))
 print("last stamp - earliest first stamp: %d cycles" % (t[:, 5].max() - t[:, 0].min()))
