@@ -178,7 +178,10 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
           double dd2 = 0.0;
 #pragma unroll
           for (int k = 0; k < NV; k++) dd2 += mk[k] * Dh[k] * Dh[k];
-          if (ct && !((active >> h) & 1ull) && sh_ < -tol) key = hex_pack_key(-(sh_ * sh_) * fast_rcp(dd2), h);
+          // a violated row whose image has no free part (linearly dependent on the active ones) must still be
+          // picked -- the dependent-step logic below resolves or reports it -- so it gets the largest finite gain
+          if (ct && !((active >> h) & 1ull) && sh_ < -tol)
+            key = hex_pack_key((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
         } else {
           if (ct && !((active >> h) & 1ull)) key = hex_pack_key(sh_, h);
         }
