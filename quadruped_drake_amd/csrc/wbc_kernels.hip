@@ -23,6 +23,7 @@ __device__ unsigned long long g_wbc_stamps[16 * 4096];
 #include "wbc_tick.hpp"
 #include "wbc_quad.hpp"
 #include "wbc_hex.hpp"
+#include "wbc_traj_dev.hpp"
 
 namespace {
 
@@ -551,6 +552,143 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   WBC_STAMP(5);
 }
 
+// ---------------------------------------------------------------- persistent closed loop
+// `steps` ticks of  lookup(time) -> tick -> semi-implicit Euler -> time += dt  inside ONE launch: every wavefront
+// runs its four robots' whole rollout on its own, the state (q, v) lives in the LDS input buffer between ticks.
+// No launch boundaries, no start-up latency per tick, and -- because the wavefronts never wait for each other --
+// the per-tick active-set tail of the slowest robot averages out over the rollout instead of ending every launch.
+// Arithmetic is identical to the launch-per-stage path (wbc_integrate_kernel, traj_lookup_kernel): the two agree
+// bit for bit (tests/test_rollout.py).
+template <int KIND, bool TB>
+__global__ void __launch_bounds__(HEX_BLOCK)
+wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld, int steps,
+                       double dt, wbc::TrajDev T, double* __restrict__ q, double* __restrict__ v, double* __restrict__ time,
+                       double* __restrict__ tg, uint8_t* __restrict__ mask, const double* __restrict__ mu,
+                       const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
+                       int32_t* __restrict__ status, StatsDev* __restrict__ stats, double* __restrict__ vdot) {
+  constexpr int PER_LANE = (NIN * HROBOTS + HEX_BLOCK - 1) / HEX_BLOCK;
+  constexpr int MPER = (MODEL_PAD_WORDS + HEX_BLOCK - 1) / HEX_BLOCK;
+  constexpr int NST = 37;   // state rows q (19) + v (18)
+  __shared__ double mbuf[MPER * HEX_BLOCK];
+  __shared__ double inbuf[PER_LANE * HEX_BLOCK];
+  __shared__ double parkbuf[HROBOTS * wbc::PK_N];
+  __shared__ double vdbuf[HROBOTS * 18];
+  const int slot = threadIdx.x >> 4;
+  const int i = blockIdx.x * HROBOTS + slot;
+  const bool live = i < n;
+  const int ii = live ? i : (n - 1);
+  HexDev qo;
+  const int h = qo.h;
+  const bool lead = h == 0;
+  {
+    const double* msrc = reinterpret_cast<const double*>(mp) + (size_t)(blockIdx.x % MODEL_REPLICAS) * MODEL_PAD_WORDS;
+#pragma unroll
+    for (int j = 0; j < MPER; j++) mbuf[j * HEX_BLOCK + threadIdx.x] = msrc[min(j * HEX_BLOCK + (int)threadIdx.x, MODEL_PAD_WORDS - 1)];
+    // own robot's state rows: lane h takes rows h, h+16, h+32 (< 37)
+#pragma unroll
+    for (int r = h; r < NST; r += 16)
+      inbuf[r * HROBOTS + slot] = (r < 19) ? q[(size_t)r * ld + ii] : v[(size_t)(r - 19) * ld + ii];
+    for (int r = h; r < 18; r += 16) vdbuf[slot * 18 + r] = vdot[(size_t)r * ld + ii];
+  }
+  double tnow = time[ii];
+  const double mu_in = mu ? mu[ii] : 0.0, msi = ms ? ms[ii] : 1.0;
+  __syncthreads();
+  const wbc::ModelC& m = *reinterpret_cast<const wbc::ModelC*>(mbuf);
+  const wbc::ParamsC& P = *pp;
+  const double mui = mu ? mu_in : P.mu;
+  auto in = [&](int r) -> double { return inbuf[r * HROBOTS + slot]; };
+  ParkLds park(parkbuf + slot * wbc::PK_N);
+  int hint = T.K / 2;
+  for (int step = 0; step < steps; step++) {
+    const bool last = step == steps - 1;
+    // ---- targets and contact mask of this tick (planners/towr.py:92-148)
+    const int c = wbc::traj_index(T, tnow, hint);
+    hint = c < 0 ? hint : c;
+    const double* src = c < 0 ? T.standing : T.table + (size_t)c * 54;
+    const unsigned mk = (c < 0 ? T.standing_mask : T.masks[c]) & 0xF;
+#pragma unroll
+    for (int e = h; e < 54; e += 16) {
+      const double x = src[e];
+      inbuf[(NST + e) * HROBOTS + slot] = x;
+      if (last && live) tg[(size_t)e * ld + ii] = x;
+    }
+    if (last && live && lead) mask[ii] = (uint8_t)mk;
+    __syncthreads();
+    // ---- the tick
+    double tsum = 0.0, tmax = 0.0, errv = 0.0;
+    auto ot = [&](int k, double x) {
+      if (last && live) tau[(size_t)k * ld + ii] = x;
+      tsum += fabs(x);
+      tmax = fmax(tmax, fabs(x));
+    };
+    auto om = [&](int k, double x) {
+      if (k >= 4) {
+        if (k >= 10 || lead) {
+          vdbuf[slot * 18 + (k - 4)] = x;
+          if (last && live) vdot[(size_t)(k - 4) * ld + ii] = x;
+        }
+        return;
+      }
+      if (last && live && lead && met) met[(size_t)k * ld + ii] = x;
+      if (k == 1) errv = x;
+    };
+    int iters = 0;
+    const int st = wbc::hex_tick<HexDev, KIND, TB>(m, P, qo, in, mk, mui, msi, park, ot, om, &iters);
+    if (last && live && lead && status) status[ii] = st;
+    if (stats) {
+      const double ts = qo.sum16(tsum), tm = qo.max16(tmax);
+      if (live && lead) {
+        StatsDev* sd = stats + (blockIdx.x & (STAT_SLOTS - 1));
+        atomicAdd(&sd->ticks, 1.0);
+        if (st != 0) atomicAdd(&sd->status_nonzero, 1.0);
+        atomicAdd(&sd->iters_sum, (double)iters);
+        atomicAdd(&sd->tau_abs_sum, ts);
+        atomicMax(&sd->tau_abs_max_bits, (unsigned long long)__double_as_longlong(tm));
+        atomicAdd(&sd->err_sum, errv);
+        atomicAdd(&sd->mask_count[mk], 1.0);
+      }
+    }
+    __syncthreads();
+    // ---- forward step, same arithmetic as wbc_integrate_kernel: v+ = v + dt vd; orientation by exp(dt/2 w+); p, joints by v+
+#pragma unroll
+    for (int r = h; r < 18; r += 16) {
+      const double vn = inbuf[(19 + r) * HROBOTS + slot] + dt * vdbuf[slot * 18 + r];
+      inbuf[(19 + r) * HROBOTS + slot] = vn;
+      if (r >= 3) inbuf[(4 + (r - 3)) * HROBOTS + slot] += dt * vn;   // q rows 4..18 <- v rows 3..17
+    }
+    __syncthreads();
+    if (lead) {
+      const double w0 = in(19), w1 = in(20), w2 = in(21);
+      const double wn = sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+      const double ang = 0.5 * wn * dt;
+      double dw = 1.0, dx = 0.0, dy = 0.0, dz = 0.0;
+      if (wn > 0.0) {
+        const double sc = sin(ang) / wn;
+        dw = cos(ang); dx = sc * w0; dy = sc * w1; dz = sc * w2;
+      }
+      const double w1q = in(0), x1 = in(1), y1 = in(2), z1 = in(3);
+      double qw = dw * w1q - dx * x1 - dy * y1 - dz * z1;
+      double qx = dw * x1 + dx * w1q + dy * z1 - dz * y1;
+      double qy = dw * y1 - dx * z1 + dy * w1q + dz * x1;
+      double qz = dw * z1 + dx * y1 - dy * x1 + dz * w1q;
+      const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+      inbuf[0 * HROBOTS + slot] = qw * inv; inbuf[1 * HROBOTS + slot] = qx * inv;
+      inbuf[2 * HROBOTS + slot] = qy * inv; inbuf[3 * HROBOTS + slot] = qz * inv;
+    }
+    tnow += dt;
+    __syncthreads();
+  }
+  // ---- state back to HBM
+  if (live) {
+#pragma unroll
+    for (int r = h; r < NST; r += 16) {
+      const double x = inbuf[r * HROBOTS + slot];
+      if (r < 19) q[(size_t)r * ld + ii] = x; else v[(size_t)(r - 19) * ld + ii] = x;
+    }
+    if (lead) time[ii] = tnow;
+  }
+}
+
 // ---------------------------------------------------------------- forward step
 // Semi-implicit Euler in the reference's coordinates: v = [w_WB (world); v_WBo (world); qd].
 __global__ void wbc_integrate_kernel(int n, int ld, double dt, double* __restrict__ q, double* __restrict__ v,
@@ -617,6 +755,8 @@ struct wbc_handle_s {
   uint8_t* s_mask;
   int32_t* s_status;
 };
+
+extern "C" int wbc_traj_raw_(wbc_traj t, wbc::TrajDev* out);   // wbc_traj.hip (internal)
 
 extern "C" {
 
@@ -912,6 +1052,31 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
   int rc = check_step_args(h, n, ld, q, v, targets, contact_mask, tau);
   if (rc) return rc;
   if (h->flags & WBC_HOST_PTRS) return misuse("wbc_rollout: needs a WBC_DEVICE_PTRS handle");
+  if (steps == 0 || n == 0) return 0;
+  HIP_TRY(hipSetDevice(h->device));
+  if (pick_variant(h, n) == 3) {
+    // 16-lane mapping: the whole rollout is ONE persistent launch (wbc_hex_rollout_kernel)
+    wbc::TrajDev T;
+    if (wbc_traj_raw_(traj, &T)) return misuse("wbc_rollout: bad trajectory handle");
+    h->last_variant = 3;
+    StatsDev* d_stats = getenv("WBC_NO_STATS") ? nullptr : h->d_stats;
+    dim3 grid((n + HROBOTS - 1) / HROBOTS);
+#define WBC_RO_ARGS grid, dim3(HEX_BLOCK), 0, h->stream, h->d_model, h->d_params, n, ld, steps, dt, T, q, v, time, targets, \
+                    contact_mask, mu, mass_scale, tau, metrics, status, d_stats, vdot
+#define WBC_RO_KIND(TBV)                                                                                   \
+    switch (h->kind) {                                                                                     \
+      case WBC_KIND_ID: hipLaunchKernelGGL((wbc_hex_rollout_kernel<wbc::KIND_ID, TBV>), WBC_RO_ARGS); break;     \
+      case WBC_KIND_MPTC: hipLaunchKernelGGL((wbc_hex_rollout_kernel<wbc::KIND_MPTC, TBV>), WBC_RO_ARGS); break; \
+      case WBC_KIND_PC: hipLaunchKernelGGL((wbc_hex_rollout_kernel<wbc::KIND_PC, TBV>), WBC_RO_ARGS); break;     \
+      default: hipLaunchKernelGGL((wbc_hex_rollout_kernel<wbc::KIND_CLF, TBV>), WBC_RO_ARGS);                    \
+    }
+    if (h->torque_box) { WBC_RO_KIND(true) } else { WBC_RO_KIND(false) }
+#undef WBC_RO_KIND
+#undef WBC_RO_ARGS
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  // other mappings: one launch per stage (lookup, tick, forward step, time)
   double* saved = h->d_vdot;
   h->d_vdot = vdot;
   for (int s = 0; s < steps && rc == 0; s++) {

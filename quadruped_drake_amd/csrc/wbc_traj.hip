@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "../../include/wbc.h"
+#include "wbc_traj_dev.hpp"
 
 namespace {
 thread_local char g_terr[256] = "";
@@ -30,36 +31,14 @@ inline const uint8_t* rd3(const uint8_t* p, double* out) {
   return p + 24;
 }
 
-// One thread per robot: binary search in the non-decreasing timestamps, nearest sample, first index
-// on ties and among equal timestamps (what np.abs(ts - t).argmin() returns), then a 54-double gather.
-__global__ void traj_lookup_kernel(int n, int ld, int K, double wait_time, const double* __restrict__ time,
-                                   const double* __restrict__ ts, const double* __restrict__ table,
-                                   const uint8_t* __restrict__ masks, const double* __restrict__ standing,
-                                   uint8_t standing_mask, double* __restrict__ targets,
-                                   uint8_t* __restrict__ contact_mask) {
+// One thread per robot: nearest sample (wbc_traj_dev.hpp), then a 54-double gather.
+__global__ void traj_lookup_kernel(int n, int ld, wbc::TrajDev T, const double* __restrict__ time,
+                                   double* __restrict__ targets, uint8_t* __restrict__ contact_mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double t = time[i];
-  const double* src;
-  uint8_t mk;
-  if (t < wait_time || K == 0) {
-    src = standing;
-    mk = standing_mask;
-  } else {
-    t -= wait_time;
-    int lo = 0, hi = K;  // first index with ts[idx] >= t
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (ts[mid] < t) lo = mid + 1; else hi = mid;
-    }
-    int c;
-    if (lo == 0) c = 0;
-    else if (lo == K) c = K - 1;
-    else c = (fabs(ts[lo - 1] - t) <= fabs(ts[lo] - t)) ? lo - 1 : lo;
-    while (c > 0 && ts[c - 1] == ts[c]) c--;
-    src = table + (size_t)c * 54;
-    mk = masks[c];
-  }
+  const int c = wbc::traj_index(T, time[i], T.K / 2);
+  const double* src = c < 0 ? T.standing : T.table + (size_t)c * 54;
+  const uint8_t mk = c < 0 ? T.standing_mask : T.masks[c];
   for (int r = 0; r < 54; r++) targets[(size_t)r * ld + i] = src[r];
   contact_mask[i] = mk;
 }
@@ -147,10 +126,17 @@ int wbc_traj_lookup(wbc_traj t, void* hip_stream, int n, int ld, const double* t
   if (!t || n < 0 || (n > 0 && (ld < n || !time || !targets || !contact_mask))) return -1;
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(t->device));
-  hipLaunchKernelGGL(traj_lookup_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, n, ld, t->K,
-                     t->wait_time, time, t->d_ts, t->d_table, t->d_masks, t->d_standing, t->standing_mask, targets,
-                     contact_mask);
+  wbc::TrajDev T{t->K, t->wait_time, t->d_ts, t->d_table, t->d_masks, t->d_standing, t->standing_mask};
+  hipLaunchKernelGGL(traj_lookup_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, n, ld, T, time,
+                     targets, contact_mask);
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// internal (not in include/wbc.h): the trajectory's device pointers for the persistent rollout kernel
+int wbc_traj_raw_(wbc_traj t, wbc::TrajDev* out) {
+  if (!t || !out) return -1;
+  *out = wbc::TrajDev{t->K, t->wait_time, t->d_ts, t->d_table, t->d_masks, t->d_standing, t->standing_mask};
   return 0;
 }
 

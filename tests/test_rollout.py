@@ -125,3 +125,66 @@ def test_closed_loop_mptc_is_passive():
     assert (np.diff(Vs, axis=0) <= 1e-12).all() and (Vs[-1] < 0.6 * Vs[0]).all()    # V decreases monotonically
     assert np.abs(v.cpu().numpy()).max() < 1.0
     ctrl.close()
+
+
+def _trot_trajectory(K=300, dt=1e-3, seed=7):
+    """A synthetic stored trunk trajectory: alternating diagonal-pair contacts every 60 samples, targets = the
+    standing targets with a slow body sway and lifted swing feet (what a TOWR trot would stream)."""
+    rng = np.random.default_rng(seed)
+    st_t = workloads.standing_targets("mini_cheetah", 1)[:, 0]
+    ts = np.arange(K) * dt
+    ts[40] = ts[39]                                     # a duplicated timestamp (first index must win)
+    tg = np.tile(st_t, (K, 1))
+    tg[:, 0] += 0.01 * np.sin(2 * np.pi * ts / 0.3)     # body x sway
+    tg[:, 3] = 0.01 * 2 * np.pi / 0.3 * np.cos(2 * np.pi * ts / 0.3)
+    masks = np.where((np.arange(K) // 60) % 2 == 0, 0b1001, 0b0110).astype(np.uint8)
+    for f in range(4):
+        sw = ((masks >> f) & 1) == 0
+        tg[sw, 18 + 9 * f + 2] += 0.03                  # swing foot z target
+    return ts, tg, masks, st_t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["mptc", "id"])
+def test_persistent_rollout_equals_launch_per_stage(kind):
+    """wbc_rollout on the 16-lane mapping is ONE persistent launch (state in LDS between ticks, lookup with an
+    index hint, in-kernel forward step); it must reproduce the launch-per-stage loop (wbc_traj_lookup, wbc_step,
+    wbc_integrate, time += dt) bit for bit -- contact switches, per-robot time offsets and the wait phase included."""
+    import torch
+    from quadruped_drake_amd import IDController, MPTCController
+    from quadruped_drake_amd.trajectory import TrunkTrajectory
+    n, steps, dt = 203, 120, 1e-3
+    ts, tg, masks, st_t = _trot_trajectory()
+    traj = TrunkTrajectory(ts, tg, masks, wait_time=0.03, device=0, standing_targets=st_t, standing_mask=0b1111)
+    q0, v0 = workloads.nominal_state("mini_cheetah", n)
+    rng = np.random.default_rng(11)
+    q0[7:] += rng.uniform(-0.05, 0.05, (12, n)); v0[0:6] = rng.normal(0, 0.05, (6, n))
+    t0 = rng.uniform(0.0, 0.25, n)                       # some robots start inside the wait phase, some past the table's end
+    cls = MPTCController if kind == "mptc" else IDController
+    dev = "cuda:0"
+    # (a) persistent
+    ca = cls(max_batch=n, device=0); ca.set_variant("hex")
+    qa = torch.tensor(q0, device=dev); va = torch.tensor(v0, device=dev); ta = torch.tensor(t0, device=dev)
+    tau_a, met_a, st_a, tg_a, mk_a = ca.rollout(traj, steps, dt, qa, va, ta)
+    ca.sync()
+    sa = ca.stats()
+    # (b) one launch per stage, same kernels' arithmetic
+    cb = cls(max_batch=n, device=0); cb.set_variant("hex")
+    qb = torch.tensor(q0, device=dev); vb = torch.tensor(v0, device=dev); tb = torch.tensor(t0, device=dev)
+    vd = torch.zeros((18, n), dtype=torch.float64, device=dev)
+    cb.set_vdot_output(vd)
+    for _ in range(steps):
+        tg_b, mk_b = traj.lookup(tb)
+        torch.cuda.synchronize()
+        tau_b, met_b, st_b = cb.step(qb, vb, tg_b, mk_b)
+        cb.integrate(qb, vb, vd, dt)
+        cb.sync()
+        tb += dt
+    sb = cb.stats()
+    for a, b in ((qa, qb), (va, vb), (ta, tb), (tau_a, tau_b), (met_a, met_b), (tg_a, tg_b)):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    assert np.array_equal(st_a.cpu().numpy(), st_b.cpu().numpy()) and np.array_equal(mk_a.cpu().numpy(), mk_b.cpu().numpy())
+    assert sa["ticks"] == sb["ticks"] == steps * n and sa["status_nonzero"] == sb["status_nonzero"]
+    assert sa["iters_sum"] == sb["iters_sum"] and sa["mask_count"] == sb["mask_count"]
+    assert len(set(mk_a.cpu().numpy().tolist())) >= 2     # the batch really was in different contact phases
+    ca.close(); cb.close()
