@@ -66,6 +66,35 @@ def cpu_baseline(batch, seconds):
                       "restatement of the Drake+OSQP tick" % (n, reps)}
 
 
+def closed_loop(shard, device, steps=300):
+    """Closed-loop rate of the same law (wbc_rollout: lookup -> tick -> forward step, one persistent launch):
+    nominal standing states with small perturbations, standing targets, dt = 1 ms (MPTC) / 5 ms (ID)."""
+    import numpy as np
+    import torch
+    from quadruped_drake_amd import IDController, MPTCController, workloads
+    from quadruped_drake_amd.trajectory import TrunkTrajectory
+    n = shard["n"]
+    cls, dt = (IDController, 5e-3) if shard["kind"] == "id" else (MPTCController, 1e-3)
+    q0, v0 = workloads.nominal_state(shard["model"], n)
+    rng = np.random.default_rng(0)
+    q0[7:] += rng.uniform(-0.05, 0.05, (12, n)); v0[0:6] = rng.normal(0, 0.05, (6, n))
+    st_t = workloads.standing_targets(shard["model"], 1)[:, 0]
+    traj = TrunkTrajectory(np.zeros(0), np.zeros((0, 54)), np.zeros(0, np.uint8), wait_time=1e9, device=device,
+                           standing_targets=st_t, standing_mask=0b1111, model=shard["model"])
+    ctrl = cls(model=shard["model"], max_batch=n, device=device)
+    dev = torch.device("cuda", device)
+    q = torch.tensor(q0, device=dev); v = torch.tensor(v0, device=dev); t = torch.zeros(n, dtype=torch.float64, device=dev)
+    ctrl.rollout(traj, 20, dt, q, v, t); ctrl.sync()
+    t0 = time.perf_counter()
+    ctrl.rollout(traj, steps, dt, q, v, t); ctrl.sync()
+    el = time.perf_counter() - t0
+    bad = ctrl.stats()["status_nonzero"]
+    ctrl.close()
+    return {"ticks_per_s": n * steps / el, "us_per_step": el / steps * 1e6, "steps": steps, "dt": dt, "status_nonzero": bad,
+            "scenario": "%d x %s standing, %s, targets from the stored-trajectory lookup, semi-implicit Euler forward step; "
+                        "one persistent launch for the whole rollout" % (n, shard["model"], shard["kind"].upper())}
+
+
 def main():
     a = parse()
     import numpy as np
@@ -166,6 +195,7 @@ def main():
             "kernel_info": ctrl.kernel_info(),
         }
         if world == 1 and not a.no_cpu_baseline:
+            line["closed_loop"] = closed_loop(shard, local)          # informational, outside the timed region
             line["cpu_baseline"] = cpu_baseline(batch, a.cpu_seconds)
             tau_gpu = out[0][:, :256].cpu().numpy()
             from oracle import oracle_py as orc

@@ -142,7 +142,10 @@ int wbc_integrate(wbc_handle h, int n, int ld, double dt, double* q, double* v, 
 /* `steps` closed-loop ticks entirely on the device: targets/contact from `traj` at time[i]
  * (wbc_traj_lookup), wbc_step, wbc_integrate, time += dt.  q, v, time, targets, contact_mask, tau,
  * vdot are device buffers ([..][ld]); metrics/status may be NULL.  Statistics accumulate in the
- * handle (wbc_stats_get).  Asynchronous on the handle's stream. */
+ * handle (wbc_stats_get).  Asynchronous on the handle's stream.  On the 16-lane kernel the whole rollout is
+ * one persistent launch (state kept on chip between ticks), bit-identical to the launch-per-stage loop;
+ * on return q, v, time hold the final state and targets / contact_mask / tau / metrics / status / vdot the
+ * last tick's values. */
 int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld, double* q, double* v,
                 double* time, double* targets, uint8_t* contact_mask, const double* mu,
                 const double* mass_scale, double* tau, double* metrics, int32_t* status, double* vdot);
