@@ -1070,7 +1070,12 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
       case WBC_KIND_PC: hipLaunchKernelGGL((wbc_hex_rollout_kernel<wbc::KIND_PC, TBV>), WBC_RO_ARGS); break;     \
       default: hipLaunchKernelGGL((wbc_hex_rollout_kernel<wbc::KIND_CLF, TBV>), WBC_RO_ARGS);                    \
     }
-    if (h->torque_box) { WBC_RO_KIND(true) } else { WBC_RO_KIND(false) }
+    // at most 1024 ticks per launch (~25 ms): long rollouts stay a sequence of bounded kernels
+    const int total = steps;
+    for (int done_steps = 0; done_steps < total; done_steps += 1024) {
+      steps = (total - done_steps < 1024) ? total - done_steps : 1024;
+      if (h->torque_box) { WBC_RO_KIND(true) } else { WBC_RO_KIND(false) }
+    }
 #undef WBC_RO_KIND
 #undef WBC_RO_ARGS
     HIP_TRY(hipGetLastError());
