@@ -188,3 +188,39 @@ def test_persistent_rollout_equals_launch_per_stage(kind):
     assert sa["iters_sum"] == sb["iters_sum"] and sa["mask_count"] == sb["mask_count"]
     assert len(set(mk_a.cpu().numpy().tolist())) >= 2     # the batch really was in different contact phases
     ca.close(); cb.close()
+
+
+@pytest.mark.gpu
+def test_persistent_rollout_long_and_ragged():
+    """More ticks than one bounded launch carries (1024) and a batch that does not fill its last wavefront:
+    still identical to the launch-per-stage loop, and the table's last sample is held after its end."""
+    import torch
+    from quadruped_drake_amd import IDController
+    from quadruped_drake_amd.trajectory import TrunkTrajectory
+    n, steps, dt = 9, 1100, 1e-3
+    ts, tg, masks, st_t = _trot_trajectory(K=200)
+    masks[:] = 0b1111                                   # keep the robots standing; the targets still vary with time
+    traj = TrunkTrajectory(ts, tg, masks, wait_time=0.01, device=0, standing_targets=st_t, standing_mask=0b1111)
+    q0, v0 = workloads.nominal_state("mini_cheetah", n)
+    t0 = np.linspace(0.0, 0.05, n)
+    dev = "cuda:0"
+    ca = IDController(max_batch=16, device=0); ca.set_variant("hex")
+    qa = torch.tensor(q0, device=dev); va = torch.tensor(v0, device=dev); ta = torch.tensor(t0, device=dev)
+    tau_a, met_a, st_a, tg_a, mk_a = ca.rollout(traj, steps, dt, qa, va, ta)
+    ca.sync()
+    cb = IDController(max_batch=16, device=0); cb.set_variant("hex")
+    qb = torch.tensor(q0, device=dev); vb = torch.tensor(v0, device=dev); tb = torch.tensor(t0, device=dev)
+    vd = torch.zeros((18, n), dtype=torch.float64, device=dev)
+    cb.set_vdot_output(vd)
+    for _ in range(steps):
+        tg_b, mk_b = traj.lookup(tb)
+        torch.cuda.synchronize()
+        tau_b, _, _ = cb.step(qb, vb, tg_b, mk_b)
+        cb.integrate(qb, vb, vd, dt)
+        cb.sync()
+        tb += dt
+    for a, b in ((qa, qb), (va, vb), (ta, tb), (tau_a, tau_b), (tg_a, tg_b)):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
+    assert np.array_equal(tg_a.cpu().numpy()[:, 0], tg[-1])          # past the end: the last sample
+    assert ca.stats()["ticks"] == steps * n
+    ca.close(); cb.close()
