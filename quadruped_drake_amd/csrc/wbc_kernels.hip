@@ -748,6 +748,7 @@ struct wbc_handle_s {
   wbc::ModelC* d_model;
   wbc::ParamsC* d_params;
   StatsDev* d_stats;
+  StatsDev* h_stats;  // pinned, device-mapped: the reduce kernel writes the totals straight into host memory
   hipEvent_t ev0, ev1;
   // staging buffers for WBC_HOST_PTRS
   double* d_vdot;  // optional [18][ld] output of the generalized accelerations (wbc_set_vdot_output)
@@ -815,6 +816,7 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
   }
   HIP_TRY(hipMemcpy(h->d_params, &P, sizeof P, hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(h->d_stats, 0, sizeof(StatsDev) * (STAT_SLOTS + 1)));
+  HIP_TRY(hipHostMalloc(&h->h_stats, sizeof(StatsDev), hipHostMallocMapped));
   HIP_TRY(hipEventCreate(&h->ev0));
   HIP_TRY(hipEventCreate(&h->ev1));
   if (flags & WBC_HOST_PTRS) {
@@ -836,6 +838,7 @@ int wbc_destroy(wbc_handle h) {
   void* bufs[] = {h->d_model, h->d_params, h->d_stats, h->s_q, h->s_v, h->s_tg, h->s_mu, h->s_ms,
                   h->s_tau, h->s_met, h->s_mask, h->s_status};
   for (void* b : bufs) (void)hipFree(b);
+  (void)hipHostFree(h->h_stats);
   (void)hipEventDestroy(h->ev0);
   (void)hipEventDestroy(h->ev1);
   if (h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -998,10 +1001,12 @@ int wbc_stats_get(wbc_handle h, wbc_stats* out) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   StatsDev s;
-  hipLaunchKernelGGL(wbc_stats_reduce_kernel, dim3(sizeof(StatsDev) / 8), dim3(64), 0, h->stream, h->d_stats, h->d_stats + STAT_SLOTS);
+  StatsDev* dst = nullptr;
+  HIP_TRY(hipHostGetDevicePointer((void**)&dst, h->h_stats, 0));
+  hipLaunchKernelGGL(wbc_stats_reduce_kernel, dim3(sizeof(StatsDev) / 8), dim3(64), 0, h->stream, h->d_stats, dst);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(&s, h->d_stats + STAT_SLOTS, sizeof s, hipMemcpyDeviceToHost));
+  HIP_TRY(hipStreamSynchronize(h->stream));   // the only wait: the totals are already in host memory
+  memcpy(&s, h->h_stats, sizeof s);
   out->ticks = s.ticks; out->status_nonzero = s.status_nonzero; out->iters_sum = s.iters_sum;
   out->tau_abs_sum = s.tau_abs_sum; out->err_sum = s.err_sum;
   double mx; memcpy(&mx, &s.tau_abs_max_bits, 8);
