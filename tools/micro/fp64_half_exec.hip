@@ -7,6 +7,7 @@ template <int MODE> __global__ void __launch_bounds__(64) k(double* out, int ite
   double x0 = lane, x1 = lane + 1, x2 = lane + 2, x3 = lane + 3, x4 = lane + 4, x5 = lane + 5, x6 = lane + 6, x7 = lane + 7;
   if (MODE == 1 && lane >= 32) { out[blockIdx.x * 64 + lane] = 0; return; }   // half of the wave idles
   if (MODE == 2 && lane >= 16) { out[blockIdx.x * 64 + lane] = 0; return; }
+#pragma unroll 32
   for (int i = 0; i < iters; i++) {
     x0 = fma(x0, a, 1.0); x1 = fma(x1, a, 1.0); x2 = fma(x2, a, 1.0); x3 = fma(x3, a, 1.0);
     x4 = fma(x4, a, 1.0); x5 = fma(x5, a, 1.0); x6 = fma(x6, a, 1.0); x7 = fma(x7, a, 1.0);
