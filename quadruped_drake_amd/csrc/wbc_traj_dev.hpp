@@ -2,7 +2,13 @@
 // persistent closed-loop kernel (wbc_kernels.hip): the stored trunk trajectory as plain device pointers,
 // the nearest-sample index of planners/towr.py:92-106, and the semi-implicit Euler step of the rollout.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
+#define WBC_TRAJ_HD __host__ __device__ inline
+#else
+#define WBC_TRAJ_HD inline
+#endif
+#include <math.h>
 #include <stdint.h>
 
 namespace wbc {
@@ -20,7 +26,7 @@ struct TrajDev {
 // Index of the sample np.abs(timestamps - (t - wait_time)).argmin() would return (first index on ties and among
 // equal timestamps), or -1 for the standing targets (t < wait_time, or an empty trajectory).
 // `hint`: where to start looking (any value; the previous tick's index makes the search O(1) in a rollout).
-__device__ inline int traj_index(const TrajDev& T, double t, int hint) {
+WBC_TRAJ_HD int traj_index(const TrajDev& T, double t, int hint) {
   if (t < T.wait_time || T.K == 0) return -1;
   t -= T.wait_time;
   const double* ts = T.ts;

@@ -19,7 +19,8 @@ def lib():
                 os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_tick.hpp"),
                 os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_model.hpp"),
                 os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_quad.hpp"),
-                os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_hex.hpp")]
+                os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_hex.hpp"),
+                os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_traj_dev.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off",
                                    "-o", so, srcs[0]])

@@ -112,3 +112,24 @@ def test_lookup_feeds_the_controller():
     assert ok.sum() > 100
     r = np.abs(tau.cpu().numpy() - tau_o).max(0) / np.maximum(np.abs(tau_o).max(0), 1e-3)
     assert r[ok].max() < 1e-4
+
+
+def test_hinted_index_search_equals_numpy_argmin():
+    """wbc_traj_dev.hpp::traj_index (galloping from a hint, then bisection) on the host: for ANY hint it returns
+    what np.abs(ts - (t - wait)).argmin() returns -- duplicates, ties, both ends, the wait phase, empty table."""
+    import ctypes as C
+    import host_tick as ht
+    L = ht.lib()
+    L.host_traj_index.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_double, C.c_double, C.c_int]
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        K = int(rng.integers(1, 60))
+        ts = np.sort(rng.choice(np.arange(0, 64) * 0.25, size=K, replace=True)).astype(np.float64)   # binary-exact, with duplicates
+        wait = float(rng.choice([0.0, 0.5, 2.0]))
+        p = ts.ctypes.data_as(C.POINTER(C.c_double))
+        for t in np.concatenate([rng.uniform(-1, 20, 30), ts + wait, ts + wait + 0.125, ts + wait - 0.125]):
+            want = -1 if t < wait else int(np.abs(ts - (t - wait)).argmin())
+            for hint in (-5, 0, K // 2, K - 1, K + 7, int(rng.integers(0, K))):
+                assert L.host_traj_index(p, K, wait, float(t), hint) == want, (K, wait, t, hint)
+    empty = np.zeros(1)
+    assert L.host_traj_index(empty.ctypes.data_as(C.POINTER(C.c_double)), 0, 0.0, 3.0, 0) == -1

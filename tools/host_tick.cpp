@@ -390,3 +390,12 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
   }
   return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Host instantiation of the hinted nearest-sample search of the persistent rollout (wbc_traj_dev.hpp).
+#include "../quadruped_drake_amd/csrc/wbc_traj_dev.hpp"
+extern "C" int host_traj_index(const double* ts, int K, double wait_time, double t, int hint) {
+  wbc::TrajDev T{K, wait_time, ts, nullptr, nullptr, nullptr, 0};
+  return wbc::traj_index(T, t, hint);
+}
