@@ -525,10 +525,13 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   }
   double rpy[3], E[9], rpyd[3];
   {
-    rpy[0] = atan2(R0[7], R0[8]);
-    rpy[1] = atan2(-R0[6], sqrt(R0[0] * R0[0] + R0[3] * R0[3]));
-    rpy[2] = atan2(R0[3], R0[0]);
+    // one atan2 evaluation instead of three: sub-lane i evaluates angle i (same routine, other arguments), then the
+    // three results are shared inside the quad (f64 atan2 is ~150 instructions)
     const double cp = sqrt(R0[0] * R0[0] + R0[3] * R0[3]), sp = -R0[6];
+    {
+      const double ang = atan2(pick3(sb, R0[7], -R0[6], R0[3]), pick3(sb, R0[8], cp, R0[0]));
+      rpy[0] = qo.leg_bcast(ang, 0); rpy[1] = qo.leg_bcast(ang, 1); rpy[2] = qo.leg_bcast(ang, 2);
+    }
     const double icp = 1.0 / cp;
     const double cy = R0[0] * icp, sy = R0[3] * icp;
     E[0] = cp * cy; E[1] = -sy; E[2] = 0.0; E[3] = cp * sy; E[4] = cy; E[5] = 0.0; E[6] = -sp; E[7] = 0.0; E[8] = 1.0;
@@ -580,12 +583,17 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     double qd[3];
     const double mass3[3] = {m.link[l][0].mass, m.link[l][1].mass, m.link[l][2].mass};
     {
-      double sn[3], cs[3];
+      double sn[3], cs[3], th[3];
       for (int k = 0; k < 3; k++) {
         const int row = m.q_perm[3 * l + k];
-        const double th = in(7 + row);
-        wbc_sincos(th, sn[k], cs[k]);
+        th[k] = in(7 + row);
         qd[k] = in(25 + row);
+      }
+      {
+        // sub-lane k evaluates the sine / cosine of joint k; shared inside the quad
+        double so, co;
+        wbc_sincos(pick3(sb, th[0], th[1], th[2]), so, co);
+        for (int k = 0; k < 3; k++) { sn[k] = qo.leg_bcast(so, k); cs[k] = qo.leg_bcast(co, k); }
       }
       leg_fk_vec(m, l, R0, sn, cs, K);
     }

@@ -573,6 +573,8 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* _
   __shared__ double inbuf[PER_LANE * HEX_BLOCK];
   __shared__ double parkbuf[HROBOTS * wbc::PK_N];
   __shared__ double vdbuf[HROBOTS * 18];
+  __shared__ double outbuf[HROBOTS * 18];
+  __shared__ double robuf[HROBOTS * 4];     // per robot: time, lookup hint, mu, mass scale (loop-carried, kept out of registers)   // last tick: tau (12), metrics (4), status, mask -- written to HBM once, after the loop
   const int slot = threadIdx.x >> 4;
   const int i = blockIdx.x * HROBOTS + slot;
   const bool live = i < n;
@@ -590,51 +592,57 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* _
       inbuf[r * HROBOTS + slot] = (r < 19) ? q[(size_t)r * ld + ii] : v[(size_t)(r - 19) * ld + ii];
     for (int r = h; r < 18; r += 16) vdbuf[slot * 18 + r] = vdot[(size_t)r * ld + ii];
   }
-  double tnow = time[ii];
-  const double mu_in = mu ? mu[ii] : 0.0, msi = ms ? ms[ii] : 1.0;
+  if (lead) {
+    robuf[slot * 4 + 0] = time[ii];
+    robuf[slot * 4 + 1] = (double)(T.K / 2);
+    robuf[slot * 4 + 2] = mu ? mu[ii] : pp->mu;
+    robuf[slot * 4 + 3] = ms ? ms[ii] : 1.0;
+  }
   __syncthreads();
-  const wbc::ModelC& m = *reinterpret_cast<const wbc::ModelC*>(mbuf);
-  const wbc::ParamsC& P = *pp;
-  const double mui = mu ? mu_in : P.mu;
   auto in = [&](int r) -> double { return inbuf[r * HROBOTS + slot]; };
   ParkLds park(parkbuf + slot * wbc::PK_N);
-  int hint = T.K / 2;
   for (int step = 0; step < steps; step++) {
-    const bool last = step == steps - 1;
+    // The model table and the parameters are loop-invariant, and the compiler would hoist ~130 doubles of them out
+    // of the step loop into registers (the kernel then spills): an opaque zero offset per iteration keeps those
+    // reads where the tick uses them.
+    int zoff = 0;
+    asm volatile("" : "+v"(zoff));
+    // the same for everything derived from the lane id (dozens of per-lane predicate masks would otherwise live in
+    // SGPR pairs across the whole loop body)
+    qo.h = h + zoff;
+    const wbc::ModelC& m = *reinterpret_cast<const wbc::ModelC*>(mbuf + zoff);
+    const wbc::ParamsC* ppi = pp;
+    asm volatile("" : "+s"(ppi));
+    const wbc::ParamsC& P = *ppi;
+    const double tnow = robuf[slot * 4 + 0], mui = robuf[slot * 4 + 2], msi = robuf[slot * 4 + 3];
+    const int hint = (int)robuf[slot * 4 + 1];
     // ---- targets and contact mask of this tick (planners/towr.py:92-148)
     const int c = wbc::traj_index(T, tnow, hint);
-    hint = c < 0 ? hint : c;
     const double* src = c < 0 ? T.standing : T.table + (size_t)c * 54;
     const unsigned mk = (c < 0 ? T.standing_mask : T.masks[c]) & 0xF;
 #pragma unroll
     for (int e = h; e < 54; e += 16) {
-      const double x = src[e];
-      inbuf[(NST + e) * HROBOTS + slot] = x;
-      if (last && live) tg[(size_t)e * ld + ii] = x;
+      inbuf[(NST + e) * HROBOTS + slot] = src[e];
     }
-    if (last && live && lead) mask[ii] = (uint8_t)mk;
     __syncthreads();
     // ---- the tick
     double tsum = 0.0, tmax = 0.0, errv = 0.0;
     auto ot = [&](int k, double x) {
-      if (last && live) tau[(size_t)k * ld + ii] = x;
+      outbuf[slot * 18 + k] = x;
       tsum += fabs(x);
       tmax = fmax(tmax, fabs(x));
     };
     auto om = [&](int k, double x) {
       if (k >= 4) {
-        if (k >= 10 || lead) {
-          vdbuf[slot * 18 + (k - 4)] = x;
-          if (last && live) vdot[(size_t)(k - 4) * ld + ii] = x;
-        }
+        if (k >= 10 || lead) vdbuf[slot * 18 + (k - 4)] = x;
         return;
       }
-      if (last && live && lead && met) met[(size_t)k * ld + ii] = x;
+      if (lead) outbuf[slot * 18 + 12 + k] = x;
       if (k == 1) errv = x;
     };
     int iters = 0;
     const int st = wbc::hex_tick<HexDev, KIND, TB>(m, P, qo, in, mk, mui, msi, park, ot, om, &iters);
-    if (last && live && lead && status) status[ii] = st;
+    if (lead) { outbuf[slot * 18 + 16] = (double)st; outbuf[slot * 18 + 17] = (double)mk; }
     if (stats) {
       const double ts = qo.sum16(tsum), tm = qo.max16(tmax);
       if (live && lead) {
@@ -675,17 +683,28 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* _
       inbuf[0 * HROBOTS + slot] = qw * inv; inbuf[1 * HROBOTS + slot] = qx * inv;
       inbuf[2 * HROBOTS + slot] = qy * inv; inbuf[3 * HROBOTS + slot] = qz * inv;
     }
-    tnow += dt;
+    if (lead) {
+      robuf[slot * 4 + 0] = tnow + dt;
+      if (c >= 0) robuf[slot * 4 + 1] = (double)c;
+    }
     __syncthreads();
   }
-  // ---- state back to HBM
+  // ---- final state and the last tick's outputs back to HBM
   if (live) {
 #pragma unroll
     for (int r = h; r < NST; r += 16) {
       const double x = inbuf[r * HROBOTS + slot];
       if (r < 19) q[(size_t)r * ld + ii] = x; else v[(size_t)(r - 19) * ld + ii] = x;
     }
-    if (lead) time[ii] = tnow;
+    for (int e = h; e < 54; e += 16) tg[(size_t)e * ld + ii] = inbuf[(NST + e) * HROBOTS + slot];
+    for (int r = h; r < 18; r += 16) vdot[(size_t)r * ld + ii] = vdbuf[slot * 18 + r];
+    if (h < 12) tau[(size_t)h * ld + ii] = outbuf[slot * 18 + h];
+    else if (met) met[(size_t)(h - 12) * ld + ii] = outbuf[slot * 18 + h];
+    if (lead) {
+      time[ii] = robuf[slot * 4 + 0];
+      mask[ii] = (uint8_t)(int)outbuf[slot * 18 + 17];
+      if (status) status[ii] = (int32_t)outbuf[slot * 18 + 16];
+    }
   }
 }
 
