@@ -9,13 +9,21 @@ the rank's shard) over a synthetic randomised-state batch that is resident in HB
 timed region starts.  Per-GPU work is fixed at 4096 Mini-Cheetah instances (weak scaling):
   N = 1 : BASELINE.json configs[2] -- 4096 Mini Cheetah, trot contact modes, MPTC controller;
   N > 1 : BASELINE.json configs[4] pattern -- 4096*N instances with per-instance mu / mass scale,
-          sharded contiguously, no data-path collective; one RCCL all-reduce of the end-of-rollout
+          sharded contiguously, no data-path collective; one RCCL all-gather of the end-of-rollout
           statistics vector closes the timed region.
+Launching: under torch.distributed.run the rank environment is used as given.  Plain
+`python bench.py --gpus N` (no WORLD_SIZE in the environment) SELF-LAUNCHES: the parent -- which never
+imports torch or touches a GPU -- starts N fresh child processes of this file (one rank per GPU,
+127.0.0.1 rendezvous), relays rank 0's JSON line and exits non-zero if any child does.
+`--backend gloo` is the CPU test switch: without a GPU it runs launch + shard + statistics exchange
+only (`"dry_run": true`, no kernel, no throughput claim) -- tests/test_bench_launch_cpu.py.
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,32 +46,132 @@ def parse():
     ap.add_argument("--per-gpu", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--config", type=int, default=0, help="override workload config (2,3,4,5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--variant", default="auto", choices=["auto", "lane", "quad", "hex"], help="kernel variant (A/B runs)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work (core-seconds) for the baseline sample")
+    ap.add_argument("--variant", default="auto", choices=["auto", "hex"], help="kernel variant (one product family)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU work (seconds) for the baseline sample")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; gloo = CPU test switch (dry run without a GPU)")
+    ap.add_argument("--dry-run", action="store_true", help="launch + shard + statistics exchange only, no kernel")
+    ap.add_argument("--launch-timeout", type=float, default=1800.0, help="self-launch: seconds before the children are stopped")
     return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ self-launch
+def self_launch(a):
+    """Parent of a plain `python bench.py --gpus N`: N fresh rank processes, no GPU touched here."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    deadline = time.time() + a.launch_timeout
+    rc = 0
+    # poll every child: one rank dying must not leave the others waiting at the rendezvous until the timeout
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+            rc = 124 if time.time() > deadline else 1
+            break
+        time.sleep(0.1)
+    for r, p in enumerate(procs):
+        if p.poll() is None:            # stop exactly the processes started here
+            p.kill()
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""   # one JSON line: far below the pipe buffer
+    for r, p in enumerate(procs):
+        p.wait()
+        if p.returncode != 0:
+            sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, p.returncode))
+            rc = rc or (p.returncode if p.returncode > 0 else 1)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if rc == 0 and not any(l.startswith("{") for l in out0.splitlines()):
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_limits():
+    """Host CPU resources as this process sees them: affinity, cgroup quota (cpu.max), usable threads."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    raw = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                raw = f.read().strip()
+            if path.endswith("cpu.max"):
+                q, per = raw.split()
+                quota = None if q == "max" else float(q) / float(per)
+            else:
+                q = float(raw)
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = float(f.read().strip())
+                quota = None if q <= 0 else q / per
+            break
+        except (OSError, ValueError):
+            continue
+    usable = aff if quota is None else max(1, min(aff, int(quota + 0.999)))
+    return {"nproc": os.cpu_count(), "affinity": aff, "cgroup_cpu_max": raw, "cgroup_quota_cpus": quota, "usable": usable}
 
 
 def cpu_baseline(batch, seconds):
     """Oracle (CPU restatement of the Drake+OSQP path, kind "port") on this box's host cores."""
+    import numpy as np
     from oracle import oracle_py as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    from quadruped_drake_amd import workloads
+    lim = cpu_limits()
+    cores = lim["usable"]
     m = orc.model(batch["model"]); p = orc.params(batch["kind"])
-    n0 = min(512, batch["n"])
-    sl = lambda a, n: None if a is None else (a[:, :n] if a.ndim == 2 else a[:n])
-    args = lambda n: (sl(batch["q"], n), sl(batch["v"], n), sl(batch["targets"], n), sl(batch["mask"], n),
-                      sl(batch["mu"], n), sl(batch["mass_scale"], n))
-    t = time.perf_counter()
-    orc.step_batch(batch["kind"], m, p, *args(n0), nthreads=1)
-    rate1 = n0 / (time.perf_counter() - t)
     n = batch["n"]
-    reps = max(1, int(round(rate1 * seconds / n)))
+    sl = lambda a, k: None if a is None else (a[:, :k] if a.ndim == 2 else a[:k])
+    args = lambda k: (sl(batch["q"], k), sl(batch["v"], k), sl(batch["targets"], k), sl(batch["mask"], k),
+                      sl(batch["mu"], k), sl(batch["mass_scale"], k))
+    n0 = min(512, n)
+    orc.bench_batch(batch["kind"], m, p, *args(64), nthreads=1, reps=1)      # page the library in
     t = time.perf_counter()
-    orc.bench_batch(batch["kind"], m, p, *args(n), nthreads=cores, reps=reps)   # one OpenMP region
-    dt = time.perf_counter() - t
-    return {"value": n * reps / dt, "unit": "ticks/s", "cores": cores, "kind": "port",
-            "single_core_ticks_per_s": rate1,
-            "sample": "the same %d-instance batch x %d passes (one OpenMP region, dynamic schedule), C oracle = dense "
-                      "restatement of the Drake+OSQP tick" % (n, reps)}
+    orc.bench_batch(batch["kind"], m, p, *args(n0), nthreads=1, reps=1)
+    rate1 = n0 / (time.perf_counter() - t)
+
+    def timed(threads, ticks):
+        reps = max(1, int(round(ticks / n)))
+        t0 = time.perf_counter()
+        orc.bench_batch(batch["kind"], m, p, *args(n), nthreads=threads, reps=reps)
+        return n * reps / (time.perf_counter() - t0), reps
+
+    # thread-scaling curve (about 1.5 s each): shows whether the lease really has the cores its affinity mask lists
+    curve = {}
+    for th in sorted({1, 2, 4, 8, 64, lim["affinity"]}):
+        if th > lim["affinity"]:
+            continue
+        r, _ = timed(th, rate1 * 1.5 * min(th, 8))
+        curve[str(th)] = r
+    best_threads = max(curve, key=lambda k: curve[k])
+    # the reported baseline: every usable core, ~`seconds` of wall time
+    use = int(best_threads) if curve[best_threads] > 1.15 * curve.get(str(cores), 0.0) else cores
+    rate, reps = timed(use, curve[str(use)] * seconds if str(use) in curve else rate1 * cores * seconds)
+    # BASELINE config 1 restated (SURVEY 8d): N = 1, ID law, q0 of simulate.py:171-176, standing targets,
+    # 1200 sequential ticks (6 s at dt = 5 ms, simulate.py:20-22) on ONE core
+    q0, v0 = workloads.nominal_state("mini_cheetah", 1)
+    tg0 = workloads.standing_targets("mini_cheetah", 1)
+    mk0 = np.array([0b1111], dtype=np.uint8)
+    mid = orc.model("mini_cheetah"); pid = orc.params("id")
+    orc.bench_batch("id", mid, pid, q0, v0, tg0, mk0, nthreads=1, reps=10)
+    t0 = time.perf_counter()
+    orc.bench_batch("id", mid, pid, q0, v0, tg0, mk0, nthreads=1, reps=1200)
+    c1 = time.perf_counter() - t0
+    return {"value": rate, "unit": "ticks/s", "cores": use, "kind": "port",
+            "single_core_ticks_per_s": rate1, "thread_scaling_ticks_per_s": curve, "host": lim,
+            "build": "gcc -O3 -march=x86-64-v3 -fopenmp -ffp-contract=off (oracle/Makefile)",
+            "config1": {"workload": "BASELINE configs[0] restated: 1 Mini Cheetah, ID law, q0 of simulate.py:171-176, "
+                                    "standing targets, 1200 sequential ticks, 1 core", "seconds": c1,
+                        "ticks_per_s": 1200.0 / c1, "realtime_factor_at_200Hz": (1200.0 / c1) / 200.0},
+            "sample": "the same %d-instance batch x %d passes on %d threads (one OpenMP region, dynamic schedule); C oracle = "
+                      "dense restatement of the Drake+OSQP tick, NOT Drake+OSQP" % (n, reps, use)}
 
 
 def closed_loop(shard, device, steps=300):
@@ -85,42 +193,111 @@ def closed_loop(shard, device, steps=300):
     dev = torch.device("cuda", device)
     q = torch.tensor(q0, device=dev); v = torch.tensor(v0, device=dev); t = torch.zeros(n, dtype=torch.float64, device=dev)
     ctrl.rollout(traj, 20, dt, q, v, t); ctrl.sync()
+    ctrl.stats(reset=True)
     t0 = time.perf_counter()
     ctrl.rollout(traj, steps, dt, q, v, t); ctrl.sync()
     el = time.perf_counter() - t0
-    bad = ctrl.stats()["status_nonzero"]
+    s = ctrl.stats()
     ctrl.close()
-    return {"ticks_per_s": n * steps / el, "us_per_step": el / steps * 1e6, "steps": steps, "dt": dt, "status_nonzero": bad,
+    return {"ticks_per_s": n * steps / el, "us_per_step": el / steps * 1e6, "steps": steps, "dt": dt,
+            "status_nonzero": s["status_nonzero"], "iters_per_tick": s["iters_sum"] / max(1.0, s["ticks"]),
             "scenario": "%d x %s standing, %s, targets from the stored-trajectory lookup, semi-implicit Euler forward step; "
                         "one persistent launch for the whole rollout" % (n, shard["model"], shard["kind"].upper())}
 
 
-def main():
-    a = parse()
+def large_batch(device, steps=40):
+    """The single-GPU size of BASELINE configs[4] (N = 32768, per-instance mu / mass scale) on this one GPU:
+    the large-batch roofline fraction, driver-observed (informational; `value` stays the N = 4096 line)."""
+    import torch
+    from quadruped_drake_amd import MPTCController, workloads
+    n = 32768
+    b = workloads.make_batch(5, n=n)
+    dev = torch.device("cuda", device)
+    ctrl = MPTCController(model=b["model"], max_batch=n, device=device)
+    up = lambda x: torch.tensor(x, device=dev)
+    args = [up(b[k]) for k in ("q", "v", "targets", "mask", "mu", "mass_scale")]
+    out = (torch.empty((12, n), dtype=torch.float64, device=dev), torch.empty((4, n), dtype=torch.float64, device=dev),
+           torch.empty((n,), dtype=torch.int32, device=dev))
+    for _ in range(5):
+        ctrl.step(*args, out=out)
+    ctrl.sync()
+    ms, _ = ctrl.time_steps(steps, *args, out=out)
+    bad = int((out[2] != 0).sum())
+    ctrl.close()
+    fl = FLOPS_PER_TICK[("mptc", 5)]
+    ach = fl * n / (ms * 1e-3) / 1e12
+    return {"workload": "32768 x mini_cheetah, MPTC, trot masks, per-instance mu / mass scale, ONE GPU", "steps": steps,
+            "kernel_ms": ms, "ticks_per_s": n / (ms * 1e-3), "achieved_TFLOPs": ach, "frac": ach / PEAK_FP64_VALU_TFLOPS,
+            "status_nonzero": bad}
+
+
+# ------------------------------------------------------------------------------------------------ one rank
+def run_rank(a):
     import numpy as np
     import torch
     import torch.distributed as dist
-    from quadruped_drake_amd import IDController, MPTCController, workloads
+    from quadruped_drake_amd import workloads
     from quadruped_drake_amd import stats as wstats
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, "WORLD_SIZE must equal --gpus"
+    have_gpu = torch.cuda.is_available()
+    dry = a.dry_run or (a.backend == "gloo" and not have_gpu)
+    if not dry and not have_gpu:
+        raise SystemExit("bench.py: no GPU visible -- the hot path has no CPU fallback (use --backend gloo for the dry-run test switch)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
+    dev = torch.device("cuda", local) if (have_gpu and not dry) else torch.device("cpu")
+    if dev.type == "cuda":
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    elif a.gpus > 1:
-        raise SystemExit("--gpus %d needs the torch.distributed.run launcher (one rank per GPU)" % a.gpus)
-    assert world == a.gpus, "WORLD_SIZE must equal --gpus"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    cdev = dev if a.backend == "nccl" else torch.device("cpu")       # where the collective's tensors live
 
     cfg = a.config or (3 if world == 1 else 5)
     n_total = a.per_gpu * world
     batch = workloads.make_batch(cfg, n=n_total)
     shard = wstats.shard_batch(batch, rank, world)
     n = shard["n"]
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    if dry:
+        # launch + shard + ONE statistics exchange, no kernel: what the CPU test can exercise
+        local_stats = dict(ticks=float(n * a.steps), status_nonzero=0.0, iters_sum=0.0, tau_abs_sum=0.0, tau_abs_max=0.0,
+                           err_sum=0.0, mask_count=[float((shard["mask"] == k).sum()) * a.steps for k in range(16)])
+        barrier()
+        t0 = time.perf_counter()
+        st, per_rank, seen = wstats.all_gather_stats(local_stats, device=cdev)
+        barrier()
+        dt = time.perf_counter() - t0
+        if rank == 0:
+            print(json.dumps({
+                "metric": "whole-body-QP control ticks/s at N=4096 Mini Cheetah", "value": 0.0, "unit": "ticks/s",
+                "dry_run": True, "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": None,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "backend": a.backend, "ranks_seen": seen, "per_rank_ticks": [r["ticks"] for r in per_rank],
+                "config": {"workload": "DRY RUN (no GPU): launch, shard and statistics exchange of BASELINE configs[%d]" % (cfg - 1),
+                           "instances_per_gpu": n, "parallelism": "batch-shard x%d" % world},
+                "rollout_stats": {k: st[k] for k in ("ticks", "status_nonzero", "iters_sum", "tau_abs_max")},
+                "exchange_seconds": dt}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    from quadruped_drake_amd import IDController, MPTCController
     cls = IDController if shard["kind"] == "id" else MPTCController
     ctrl = cls(model=shard["model"], max_batch=n, device=local)
     ctrl.set_variant(a.variant)
@@ -131,29 +308,25 @@ def main():
 
     for _ in range(a.warmup):
         ctrl.step(q, v, tg, mask, mu, ms, out=out)
-    wstats.all_reduce_stats(ctrl.stats(), device=dev)            # warm the statistics exchange (RCCL channel set-up) as well
+    wstats.all_gather_stats(ctrl.stats(), device=cdev)            # warm the statistics exchange (RCCL channel set-up) as well
     ctrl.stats(reset=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    sync(); barrier(); sync()
     t0 = time.perf_counter()
     # exactly K steps; HIP events on the launch stream bracket the same K launches
     ms_per_launch, _ = ctrl.time_steps(a.steps, q, v, tg, mask, mu, ms, out=out)
-    st = wstats.all_reduce_stats(ctrl.stats(), device=dev)      # end-of-rollout statistics (RCCL when world > 1)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    st, per_rank, seen = wstats.all_gather_stats(ctrl.stats(), device=cdev)   # end-of-rollout statistics (RCCL when world > 1)
+    sync(); barrier(); sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt, ms_per_launch], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt, ms_per_launch], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt, ms_per_launch = float(tt[0]), float(tt[1])
+    # per-launch distribution (outside the timed region): one HIP event between every two launches
+    each, _ = ctrl.time_steps_each(a.steps, q, v, tg, mask, mu, ms, out=out)
 
     if rank == 0:
         status = out[2].cpu().numpy()
-        used = ctrl.variant_for(n)            # "auto" resolves by batch size (include/wbc.h)
+        used = ctrl.variant_for(n)
         key = (shard["kind"], cfg)
         flops = FLOPS_PER_TICK.get(key, 37629.0)
         bpt = BYTES_PER_TICK[mu is not None]
@@ -175,40 +348,74 @@ def main():
             "value": n_total * a.steps / dt, "unit": "ticks/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic", "backend": a.backend,
+            "ranks_seen": seen, "per_rank_ticks": [r["ticks"] for r in per_rank],
             "config": {"workload": "BASELINE configs[%d]: %d x %s, %s controller, %s" % (
                 cfg - 1, n_total, shard["model"], shard["kind"].upper(),
                 "trot contact masks" if cfg != 2 else "4-contact stand"),
                 "instances_per_gpu": n, "seed": shard["seed"],
                 "domain_randomised": mu is not None, "parallelism": "batch-shard x%d" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "%s<%s>" % ({"lane": "wbc_tick_kernel", "hex": "wbc_hex_kernel", "quad": "wbc_quad_kernel"}[used], shard["kind"].upper()),
+                         "kernel": "wbc_hex_kernel<%s>" % shard["kind"].upper(),
                          "kernel_ms": ms_per_launch, "flops_per_tick": flops,
+                         "kernel_ms_dist": {"median": float(np.median(each)), "p10": float(np.percentile(each, 10)),
+                                            "p90": float(np.percentile(each, 90)), "launches": int(each.size),
+                                            "how": "one HIP event between every two launches, after the timed region"},
                          "hbm": {"achieved_GBs": bpt * n / sec / 1e9, "peak_GBs": PEAK_HBM_GBS,
                                  "frac": bpt * n / sec / 1e9 / PEAK_HBM_GBS, "bytes_per_tick": bpt},
-                         "bound_detail": "FP64 compute: priced against the dense FP64 peak (78.6 TFLOP/s, the same figure for the "
-                                         "FP64 MFMA and the FP64 vector ALU); the kernel issues vector FMAs, not MFMA (DESIGN.md section 5)",
+                         "bound_detail": "FP64 vector ALU: counted flops per tick x ticks / HIP-event launch time, priced against "
+                                         "the dense FP64 peak (78.6 TFLOP/s, the same figure for FP64 MFMA and FP64 VALU); the "
+                                         "kernel issues v_fma_f64, not MFMA (profiles/r02/micro_mfma_f64.md)",
                          "note": "HBM does not bind this path (SURVEY 8d): 864 algorithmic bytes per 37.6 kflop tick; HBM fraction stated beside it"},
             "status_nonzero": int((status != 0).sum()),
             "rollout_stats": {k: st[k] for k in ("ticks", "status_nonzero", "iters_sum", "tau_abs_max")},
+            "iters_per_tick": st["iters_sum"] / max(1.0, st["ticks"]),
             "kernel_info": ctrl.kernel_info(),
         }
         if world == 1 and not a.no_cpu_baseline:
-            line["closed_loop"] = closed_loop(shard, local)          # informational, outside the timed region
+            line["n32768"] = large_batch(local)                       # informational, outside the timed region
+            line["closed_loop"] = closed_loop(shard, local)           # informational, outside the timed region
             line["cpu_baseline"] = cpu_baseline(batch, a.cpu_seconds)
-            tau_gpu = out[0][:, :256].cpu().numpy()
+            # parity beside the number: full torque vector (tier ii) and the solver-independent accelerations (tier i)
             from oracle import oracle_py as orc
+            k = 256
+            tau_gpu = out[0][:, :k].cpu().numpy()
+            sl = lambda x: None if x is None else (x[:, :k] if x.ndim == 2 else x[:k])
             tau_o, _, _ = orc.step_batch(shard["kind"], orc.model(shard["model"]), orc.params(shard["kind"]),
-                                         batch["q"][:, :256], batch["v"][:, :256], batch["targets"][:, :256],
-                                         batch["mask"][:256], None if batch["mu"] is None else batch["mu"][:256],
-                                         None if batch["mass_scale"] is None else batch["mass_scale"][:256])
+                                         sl(batch["q"]), sl(batch["v"]), sl(batch["targets"]), sl(batch["mask"]),
+                                         sl(batch["mu"]), sl(batch["mass_scale"]))
             rel = np.abs(tau_gpu - tau_o).max(0) / np.maximum(np.abs(tau_o).max(0), 1e-3)
             line["torque_rel_err_vs_cpu_ref"] = float(rel.max())
+            vd = torch.zeros((18, n), dtype=torch.float64, device=dev)
+            ctrl.set_vdot_output(vd)
+            ctrl.step(q, v, tg, mask, mu, ms, out=out); ctrl.sync()
+            ctrl.set_vdot_output(None)
+            vdg = vd[:, :32].cpu().numpy()
+            worst = 0.0
+            mo = orc.model(shard["model"])
+            for i in range(32):
+                p = orc.params(shard["kind"])
+                if batch["mu"] is not None:
+                    p.mu = float(batch["mu"][i])
+                mi = mo if batch["mass_scale"] is None else orc.model_scaled(shard["model"], float(batch["mass_scale"][i]))
+                ct = [(int(batch["mask"][i]) >> j) & 1 for j in range(4)]
+                _, _, _, qp = orc.control_law(shard["kind"], mi, p, batch["q"][:, i], batch["v"][:, i], batch["targets"][:, i],
+                                              ct, want_qp=True)
+                worst = max(worst, float(np.abs(vdg[:, i] - qp["x"][:18]).max() / (1.0 + np.abs(qp["x"][:18]).max())))
+            line["vdot_rel_err_vs_cpu_ref_qp"] = worst          # tier (i): solver-independent part of the solution
         print(json.dumps(line))
+    ctrl.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
+    run_rank(a)
 
 
 if __name__ == "__main__":

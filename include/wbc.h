@@ -23,7 +23,7 @@
  *   contact_mask [n]   bit i set = foot i of [LF RF LH RH] in contact (`contact_states`)
  *   tau      [12][ld]  joint torques in ACTUATOR order             (basic_controller.py:37-40,320)
  *   metrics  [4][ld]   V, err, res, Vdot                            (basic_controller.py:47-50,283)
- *   status   [n]       0 optimal, 1 iteration cap, 2 singular / infeasible
+ *   status   [n]       0 optimal, 1 iteration cap, 2 singular / infeasible (tau and the accelerations are 0 then)
  *                      (the reference asserts result.is_success(): inverse_dynamics_controller.py:224)
  * Joint rows of q/v are mapped through model.q_perm (canonical joint j is read from joint row
  * q_perm[j]); torque row k is canonical joint act_perm[k]  (basic_controller.py:310-313).
@@ -124,6 +124,14 @@ int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, cons
                    const double* mass_scale, double* tau, double* metrics, int32_t* status,
                    float* ms_per_step);
 
+/* The same `steps` launches with one HIP event between every two of them: ms_each[s] = device time of launch s
+ * (for the median / p10 / p90 of SURVEY 8d's protocol; the events add ~1 us between launches, so the
+ * average of wbc_time_steps stays the headline figure).  Blocks. */
+int wbc_time_steps_each(wbc_handle h, int steps, int n, int ld, const double* q, const double* v,
+                        const double* targets, const uint8_t* contact_mask, const double* mu,
+                        const double* mass_scale, double* tau, double* metrics, int32_t* status,
+                        float* ms_each);
+
 /* Statistics since the last reset (blocks until the stream is idle). */
 int wbc_stats_get(wbc_handle h, wbc_stats* out);
 int wbc_stats_reset(wbc_handle h);
@@ -150,12 +158,11 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
                 double* time, double* targets, uint8_t* contact_mask, const double* mu,
                 const double* mass_scale, double* tau, double* metrics, int32_t* status, double* vdot);
 
-/* Kernel variant: 0 = auto (default), 1 = lane-per-robot, 2 = quad-per-robot (4 lanes = 4 legs),
- * 3 = 16 lanes (one DPP row) per robot.  All compute the same tick.  Auto: 16-lane for MPTC / PC / CLF at
- * any batch size and for ID up to n = 16384 (quad beyond).  The CLF law and the optional torque box
- * (tau_max < inf) have no quad-per-robot kernel. */
+/* Kernel variant: 0 = auto (default) or 3 = 16 lanes (one DPP row) per robot -- the one product kernel family for
+ * every law, batch size and option.  (1 = lane-per-robot and 2 = quad-per-robot were round-1 mappings that lost at
+ * every batch size and are retired: the call rejects them.) */
 int wbc_set_variant(wbc_handle h, int variant);
-/* The variant (1, 2 or 3) a wbc_step of n instances would run. */
+/* The variant a wbc_step of n instances would run (always 3). */
 int wbc_variant_for(wbc_handle h, int n);
 
 /* Kernel resource report for the variant of the most recent launch (or of max_batch before any):

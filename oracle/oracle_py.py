@@ -86,6 +86,15 @@ def model(name_or_table):
     return m
 
 
+def model_scaled(name_or_table, mass_scale):
+    """The per-instance trunk mass / inertia scale of BASELINE config 5, as orc_step_batch applies it."""
+    m = model(name_or_table)
+    m.base_mass *= mass_scale
+    for k in range(6):
+        m.base_I[k] *= mass_scale
+    return m
+
+
 def kind_index(kind):
     if isinstance(kind, str):
         return {"id": 0, "mptc": 1, "pc": 2, "clf": 3}[kind.lower()]

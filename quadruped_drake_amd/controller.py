@@ -76,10 +76,21 @@ class BatchedController:
                                 _lib.HOST_PTRS if host_ptrs else _lib.DEVICE_PTRS, C.byref(h)))
         self._h = h
         self._L = L
-        if not host_ptrs and use_torch_stream:
-            import torch
-            with torch.cuda.device(self.device):
-                _lib.check(L.wbc_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        self._torch_stream = (not host_ptrs) and use_torch_stream
+        self._bound_stream = None
+        self._bind_stream()
+
+    def _bind_stream(self):
+        """Launch on torch's CURRENT stream of this device (re-read on every call: a controller used under
+        `with torch.cuda.stream(s)` must not race with the stream it was created on)."""
+        if not self._torch_stream:
+            return None
+        import torch
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._bound_stream:
+            _lib.check(self._L.wbc_set_stream(self._h, C.c_void_p(s)))
+            self._bound_stream = s
+        return s
 
     def close(self):
         if getattr(self, "_h", None):
@@ -145,6 +156,7 @@ class BatchedController:
     def step(self, q, v, targets, contact_mask, mu=None, mass_scale=None, out=None):
         """One control tick for the batch.  Asynchronous in device mode (call sync() or use torch)."""
         n, keep, ptrs, outs = self._args(q, v, targets, contact_mask, mu, mass_scale, out)
+        self._bind_stream()
         _lib.check(self._L.wbc_step(self._h, n, n, *ptrs))
         if self.host_ptrs:
             self.sync()
@@ -155,8 +167,17 @@ class BatchedController:
         """`steps` back-to-back launches timed with HIP events on the launch stream -> ms per launch."""
         n, keep, ptrs, outs = self._args(q, v, targets, contact_mask, mu, mass_scale, out)
         ms = C.c_float(0)
+        self._bind_stream()
         _lib.check(self._L.wbc_time_steps(self._h, int(steps), n, n, *ptrs, C.byref(ms)))
         return ms.value, outs
+
+    def time_steps_each(self, steps, q, v, targets, contact_mask, mu=None, mass_scale=None, out=None):
+        """The same launches with one HIP event between every two: per-launch device milliseconds (numpy array)."""
+        n, keep, ptrs, outs = self._args(q, v, targets, contact_mask, mu, mass_scale, out)
+        ms = (C.c_float * int(steps))()
+        self._bind_stream()
+        _lib.check(self._L.wbc_time_steps_each(self._h, int(steps), n, n, *ptrs, ms))
+        return np.array(ms[:], dtype=np.float64), outs
 
     def sync(self):
         _lib.check(self._L.wbc_sync(self._h))
@@ -171,42 +192,58 @@ class BatchedController:
         return d
 
     # -- closed-loop rollouts ---------------------------------------------------
-    def set_vdot_output(self, vdot):
+    def set_vdot_output(self, vdot, n=None):
         """CUDA float64 [18, N] tensor that every step() fills with the QP's generalized accelerations (None: off)."""
-        self._vdot = vdot
-        _lib.check(self._L.wbc_set_vdot_output(self._h, C.c_void_p(vdot.data_ptr()) if vdot is not None else None))
+        if vdot is None:
+            self._vdot = None
+            _lib.check(self._L.wbc_set_vdot_output(self._h, None))
+            return
+        n = int(vdot.shape[1]) if n is None else int(n)
+        k, p = self._ptr(vdot, 18, n, np.float64, "vdot")
+        self._vdot = k
+        _lib.check(self._L.wbc_set_vdot_output(self._h, p))
 
     def integrate(self, q, v, vdot, dt):
         """Semi-implicit Euler step, in place on q [19, N] and v [18, N]."""
         n = int(q.shape[1])
-        _lib.check(self._L.wbc_integrate(self._h, n, n, float(dt), C.c_void_p(q.data_ptr()), C.c_void_p(v.data_ptr()),
-                                         C.c_void_p(vdot.data_ptr())))
+        _, pq = self._ptr(q, 19, n, np.float64, "q")
+        _, pv = self._ptr(v, 18, n, np.float64, "v")
+        _, pd = self._ptr(vdot, 18, n, np.float64, "vdot")
+        self._bind_stream()
+        _lib.check(self._L.wbc_integrate(self._h, n, n, float(dt), pq, pv, pd))
 
     def rollout(self, traj, steps, dt, q, v, time, mu=None, mass_scale=None):
         """`steps` closed-loop ticks on the device: lookup(traj, time) -> step -> integrate.  Updates q, v, time in
         place; returns the last (tau, metrics, status, targets, mask)."""
         import torch
-        n = int(q.shape[1]); dev = q.device
+        n = int(q.shape[1])
+        _, pq = self._ptr(q, 19, n, np.float64, "q")
+        _, pv = self._ptr(v, 18, n, np.float64, "v")
+        _, pt = self._ptr(time, 0, n, np.float64, "time")
+        _, pmu = self._ptr(mu, 0, n, np.float64, "mu", optional=True)
+        _, pms = self._ptr(mass_scale, 0, n, np.float64, "mass_scale", optional=True)
+        dev = q.device
         tg = torch.empty((54, n), dtype=torch.float64, device=dev); mk = torch.empty((n,), dtype=torch.uint8, device=dev)
         tau = torch.empty((12, n), dtype=torch.float64, device=dev); met = torch.empty((4, n), dtype=torch.float64, device=dev)
         st = torch.empty((n,), dtype=torch.int32, device=dev); vd = torch.empty((18, n), dtype=torch.float64, device=dev)
-        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
-        _lib.check(self._L.wbc_rollout(self._h, traj._h, int(steps), float(dt), n, n, p(q), p(v), p(time), p(tg), p(mk),
-                                       p(mu), p(mass_scale), p(tau), p(met), p(st), p(vd)))
+        p = lambda t: C.c_void_p(t.data_ptr())
+        self._bind_stream()
+        _lib.check(self._L.wbc_rollout(self._h, traj._h, int(steps), float(dt), n, n, pq, pv, pt, p(tg), p(mk),
+                                       pmu, pms, p(tau), p(met), p(st), p(vd)))
         self._keep = (tg, mk, tau, met, st, vd, mu, mass_scale)
         return tau, met, st, tg, mk
 
     def set_variant(self, variant):
-        """0 = auto, 1 = lane-per-robot kernel, 2 = quad-per-robot kernel."""
-        v = {"auto": 0, "lane": 1, "quad": 2, "hex": 3}.get(variant, variant)
+        """"auto" (0) or "hex" (3): the 16-lanes-per-robot kernel is the one product kernel family."""
+        v = {"auto": 0, "hex": 3}.get(variant, variant)
         _lib.check(self._L.wbc_set_variant(self._h, int(v)))
 
     def variant_for(self, n):
-        """Name of the kernel variant a step of n instances runs ("lane", "quad" or "hex")."""
+        """Name of the kernel variant a step of n instances runs (always "hex")."""
         v = self._L.wbc_variant_for(self._h, int(n))
         if v < 0:
             _lib.check(v)
-        return {1: "lane", 2: "quad", 3: "hex"}[v]
+        return {3: "hex"}[v]
 
     def kernel_info(self):
         a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
@@ -253,7 +290,7 @@ class PCController(BatchedController):
 
 class CLFController(BatchedController):
     """controllers/clf_controller.py:3-234 (CLF-QP inverse dynamics), batched; 13 reduced variables [z; delta]
-    (16-lane kernel: the slack lives on a spare sub-lane; also on the lane-per-robot kernel)."""
+    (the slack lives on a spare sub-lane of the 16-lane kernel)."""
     kind = _lib.KIND_CLF
 
 

@@ -999,8 +999,12 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     // rmin/rmax here are of 1/|R_cc|:  min|R| / max|R| = rmin / rmax;  a zero pivot gives inf/nan -> singular
     if (!(rmin > 1e-13 * rmax) || !(rmax < 1e300)) status = ST_SINGULAR;
     if (status == ST_SINGULAR) {
+      // reported, not solved: zero torques AND zero accelerations (include/wbc.h: every step writes vd; a rollout
+      // integrates them, so they must be defined)
       if (colv) out_tau(m.act_inv[3 * l + sb], 0.0);
       out_met(0, 0.0); out_met(1, met_err); out_met(2, 0.0); out_met(3, 0.0);
+      for (int i = 0; i < 6; i++) out_met(4 + i, 0.0);
+      if (colv) out_met(4 + 6 + m.q_perm[3 * l + sb], 0.0);
       *iters_out = 0;
       return status;
     }
@@ -1068,14 +1072,15 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     for (int k = 0; k < 6; k++) s += Yrow[k] * ab[k];
     s += Drow[0] * z0 + Drow[1] * z1 + Drow[2] * z2;
     if (colv) out_tau(m.act_inv[3 * l + sb], (status == ST_SINGULAR) ? 0.0 : s);
-    // generalized accelerations of the QP solution (rows 4..21 of out_met)
-    for (int i = 0; i < 6; i++) out_met(4 + i, ab[i]);
+    // generalized accelerations of the QP solution (rows 4..21 of out_met); zeros with the zero torques of status 2
+    const bool sing = (status == ST_SINGULAR);
+    for (int i = 0; i < 6; i++) out_met(4 + i, sing ? 0.0 : ab[i]);
     double t[3], y[3];
     cross(ab, rf, t);
     const double zl[3] = {z0, z1, z2};
     for (int i = 0; i < 3; i++) y[i] = (ct ? bc[i] : zl[i]) - (ab[3 + i] + t[i]);
     const double qdd = pick3(sb, Ji[0], Ji[3], Ji[6]) * y[0] + pick3(sb, Ji[1], Ji[4], Ji[7]) * y[1] + pick3(sb, Ji[2], Ji[5], Ji[8]) * y[2];
-    if (colv) out_met(4 + 6 + m.q_perm[3 * l + sb], qdd);
+    if (colv) out_met(4 + 6 + m.q_perm[3 * l + sb], sing ? 0.0 : qdd);
   }
   double res = 0.0;
   if (ct) res = fmax(fabs(z0) - mu * z2, fabs(z1) - mu * z2);

@@ -2,10 +2,10 @@
 //
 // Layout in HBM: struct-of-arrays, batch index fastest (row r of robot i at base[r*ld + i]).  The whole tick
 // (FK -> CRBA/RNEA -> reduced QP assembly -> QR -> active set -> torques) is ONE fused launch, so the only HBM
-// traffic is the 864 algorithmic bytes per tick.  Three mappings of a robot onto lanes, same math:
-//   wbc_hex_kernel   16 lanes (one DPP row) per robot, one QP column per lane       (wbc_hex.hpp; the default)
-//   wbc_quad_kernel   4 lanes per robot, lane = leg                                  (wbc_quad.hpp)
-//   wbc_tick_kernel   1 lane per robot (the first version; A/B reference)            (wbc_tick.hpp)
+// traffic is the 864 algorithmic bytes per tick.  One product kernel family: wbc_hex_kernel, 16 lanes (one DPP row)
+// per robot, one QP column per lane (wbc_hex.hpp).  The round-1 lane-per-robot and quad-per-robot mappings lost at
+// every batch size (profiles/r01/hex_sweep.md) and are retired; wbc_tick.hpp remains as the shared per-leg math and
+// as the host-instantiated scalar form (tests, flop counting).
 //
 // There is no CPU path in this file: if HIP fails the entry points return an error.
 #include <hip/hip_runtime.h>
@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <vector>
 
 #include "../../include/wbc.h"
 #ifdef WBC_STAMPS
@@ -21,7 +22,6 @@ __device__ unsigned long long g_wbc_stamps[16 * 4096];
 #endif
 #include "wbc_model.hpp"
 #include "wbc_tick.hpp"
-#include "wbc_quad.hpp"
 #include "wbc_hex.hpp"
 #include "wbc_traj_dev.hpp"
 
@@ -66,291 +66,10 @@ __device__ __forceinline__ double wave_max(double x) {
   return x;
 }
 
-template <int KIND>
-__global__ void __launch_bounds__(BLOCK)
-wbc_tick_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld,
-                const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
-                const uint8_t* __restrict__ mask, const double* __restrict__ mu,
-                const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
-                int32_t* __restrict__ status, StatsDev* __restrict__ stats, double* __restrict__ vdot) {
-  const int i = blockIdx.x * BLOCK + threadIdx.x;
-  const bool live = i < n;
-  const int ii = live ? i : (n - 1);  // tail lanes recompute the last robot, stores are masked
-  const wbc::ModelC& m = *mp;
-  const wbc::ParamsC& P = *pp;
-  auto in = [&](int r) -> double {
-    if (r < 19) return q[(size_t)r * ld + ii];
-    if (r < 37) return v[(size_t)(r - 19) * ld + ii];
-    return tg[(size_t)(r - 37) * ld + ii];
-  };
-  double tsum = 0.0, tmax = 0.0, errv = 0.0;
-  auto ot = [&](int k, double x) {
-    if (live) tau[(size_t)k * ld + ii] = x;
-    tsum += fabs(x);
-    tmax = fmax(tmax, fabs(x));
-  };
-  auto om = [&](int k, double x) {   // rows 0..3: metrics, rows 4..21: generalized accelerations
-    if (k >= 4) { if (live && vdot) vdot[(size_t)(k - 4) * ld + ii] = x; return; }
-    if (live && met) met[(size_t)k * ld + ii] = x;
-    if (k == 1) errv = x;
-  };
-  const unsigned mk = mask[ii] & 0xF;
-  const double mui = mu ? mu[ii] : P.mu;
-  const double msi = ms ? ms[ii] : 1.0;
-  int iters = 0;
-  const int st = wbc::tick<double, KIND>(m, P, in, mk, mui, msi, ot, om, &iters);
-  if (live && status) status[ii] = st;
-  if (stats) {
-    stats += blockIdx.x & (STAT_SLOTS - 1);
-    const double lv = live ? 1.0 : 0.0;
-    double a = wave_sum(lv), b = wave_sum(live && st != 0 ? 1.0 : 0.0), c = wave_sum(lv * iters);
-    double d = wave_sum(lv * tsum), e = wave_max(lv * tmax), f = wave_sum(lv * errv);
-    unsigned long long bal[16];
-    for (int k = 0; k < 16; k++) bal[k] = __ballot(live && mk == (unsigned)k);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&stats->ticks, a);
-      if (b != 0.0) atomicAdd(&stats->status_nonzero, b);
-      atomicAdd(&stats->iters_sum, c);
-      atomicAdd(&stats->tau_abs_sum, d);
-      atomicMax(&stats->tau_abs_max_bits, (unsigned long long)__double_as_longlong(e));
-      atomicAdd(&stats->err_sum, f);
-      for (int k = 0; k < 16; k++)
-        if (bal[k]) atomicAdd(&stats->mask_count[k], (double)__popcll(bal[k]));
-    }
-  }
-}
-
-// ---------------------------------------------------------------- v2: quad-per-robot kernel
-// Quad communication on DPP quad_perm (no LDS, no ds_bpermute): 2 v_mov_dpp per double.
-struct QuadDev {
-  int l;
-  __device__ QuadDev() : l(threadIdx.x & 3) {}
-  __device__ __forceinline__ int lane() const { return l; }
-  template <int CTRL> static __device__ __forceinline__ int dppi(int x) {
-    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);  // every quad lane is a valid source
-  }
-  template <int CTRL> static __device__ __forceinline__ double dpp(double x) {
-    int lo = __double2loint(x), hi = __double2hiint(x);
-    lo = dppi<CTRL>(lo);
-    hi = dppi<CTRL>(hi);
-    return __hiloint2double(hi, lo);
-  }
-  __device__ __forceinline__ double bcast_s(double x, int src) const {
-    switch (src) {
-      case 0: return dpp<0x00>(x);
-      case 1: return dpp<0x55>(x);
-      case 2: return dpp<0xAA>(x);
-      default: return dpp<0xFF>(x);
-    }
-  }
-  __device__ __forceinline__ double bcast_d(double x, int src) const {  // quad-uniform runtime source
-    const double a = dpp<0x00>(x), b = dpp<0x55>(x), c = dpp<0xAA>(x), d = dpp<0xFF>(x);
-    return (src & 2) ? ((src & 1) ? d : c) : ((src & 1) ? b : a);
-  }
-  __device__ __forceinline__ double sum(double x) const {
-    x += dpp<0xB1>(x);  // quad_perm [1,0,3,2]
-    x += dpp<0x4E>(x);  // quad_perm [2,3,0,1]
-    return x;
-  }
-  __device__ __forceinline__ double max(double x) const {
-    x = fmax(x, dpp<0xB1>(x));
-    x = fmax(x, dpp<0x4E>(x));
-    return x;
-  }
-  __device__ __forceinline__ bool wave_all(bool b) const { return __all(b); }  // over the active lanes
-  __device__ __forceinline__ int wave_max_int(int x) const {  // wave-uniform maximum over the active lanes
-    int m = 0;
-#pragma unroll
-    for (int b = 0; b < 4; b++) m |= (__any((x >> b) & 1) ? 1 : 0) << b;  // q <= 12: an upper bound is enough
-    return m;
-  }
-  __device__ __forceinline__ bool any(bool b) const {
-    int x = b ? 1 : 0;
-    x |= dppi<0xB1>(x);
-    x |= dppi<0x4E>(x);
-    return x != 0;
-  }
-  static __device__ __forceinline__ void amin(double& v, int& i, double ov, int oi) {
-    if (ov < v || (ov == v && oi >= 0 && (i < 0 || oi < i))) { v = ov; i = oi; }
-  }
-  __device__ __forceinline__ void argmin(double& v, int& i) const {
-    amin(v, i, dpp<0xB1>(v), dppi<0xB1>(i));
-    amin(v, i, dpp<0x4E>(v), dppi<0x4E>(i));
-  }
-};
-
-constexpr int QROBOTS = BLOCK / 4;  // robots per 64-lane block
 constexpr int NIN = 19 + 18 + 54;    // input rows per robot (q, v, targets)
-constexpr int MODEL_PAD_WORDS = 320;  // ModelC padded to 2.5 KB (multiple of BLOCK 8-byte words)
+constexpr int MODEL_PAD_WORDS = 320;  // ModelC padded to 2.5 KB (multiple of 64 8-byte words)
 constexpr int MODEL_REPLICAS = 256;   // per-block replicas of the model table in HBM
-static_assert(sizeof(wbc::ModelC) <= MODEL_PAD_WORDS * 8 && MODEL_PAD_WORDS % BLOCK == 0, "model padding");
-
-// Per-leg kinematics cache in LDS, element-major / lane-minor (element e of lane t at
-// arena[e*64 + t]): 64 consecutive doubles per element => ds_read/write_b64 are conflict-free.
-// The same arena is reused for the active-set factor (QuadShared) once the leg phase is over.
-struct LegKinLds {
-  double* a;  // arena + lane
-  // writes go through references; reads through a const LegKinLds are volatile so that the
-  // compiler re-reads LDS instead of forwarding the stored values through (scarce) registers
-  __device__ __forceinline__ double& at(int e) { return a[e * BLOCK]; }
-#ifndef WBC_KIN_VOLATILE
-#define WBC_KIN_VOLATILE 0
-#endif
-#if WBC_KIN_VOLATILE
-  __device__ __forceinline__ double ld(int e) const { return *(volatile const double*)(a + e * BLOCK); }
-#else
-  __device__ __forceinline__ double ld(int e) const { return a[e * BLOCK]; }
-#endif
-  __device__ __forceinline__ double& r(int k, int i) { return at(wbc::KIN_R + 3 * k + i); }
-  __device__ __forceinline__ double& ax(int k, int i) { return at(wbc::KIN_AX + 3 * k + i); }
-  __device__ __forceinline__ double& mcw(int k, int i) { return at(wbc::KIN_MCW + 3 * k + i); }
-  __device__ __forceinline__ double& Iw(int k, int i) { return at(wbc::KIN_IW + 6 * k + i); }
-  __device__ __forceinline__ double& rf(int i) { return at(wbc::KIN_RF + i); }
-  __device__ __forceinline__ double r(int k, int i) const { return ld(wbc::KIN_R + 3 * k + i); }
-  __device__ __forceinline__ double ax(int k, int i) const { return ld(wbc::KIN_AX + 3 * k + i); }
-  __device__ __forceinline__ double mcw(int k, int i) const { return ld(wbc::KIN_MCW + 3 * k + i); }
-  __device__ __forceinline__ double Iw(int k, int i) const { return ld(wbc::KIN_IW + 6 * k + i); }
-  __device__ __forceinline__ double rf(int i) const { return ld(wbc::KIN_RF + i); }
-};
-// Cold per-lane stage in LDS (same element-major layout).  Reads are volatile: a plain load would be
-// store-to-load forwarded, i.e. the value would stay in a register (or be spilled to scratch).
-struct StageLds {
-  double* a;        // stage base + lane (writes)
-  const double* r;  // the same address laundered through an empty asm (reads): the compiler cannot
-                    // forward the stored values (they would stay in registers or be spilled to
-                    // scratch) yet the loads stay ordinary, schedulable LDS loads (unlike volatile)
-  __device__ __forceinline__ explicit StageLds(double* p) : a(p) {
-    const double* q = p;
-    asm volatile("" : "+v"(q));
-    r = q;
-  }
-  __device__ __forceinline__ void put(int i, double v) { a[i * BLOCK] = v; }
-#ifndef WBC_STAGE_VOLATILE
-#define WBC_STAGE_VOLATILE 2
-#endif
-#if WBC_STAGE_VOLATILE == 1
-  __device__ __forceinline__ double get(int i) const { return *(volatile const double*)(a + i * BLOCK); }
-#elif WBC_STAGE_VOLATILE == 2
-  __device__ __forceinline__ double get(int i) const { return r[i * BLOCK]; }
-#else
-  __device__ __forceinline__ double get(int i) const { return a[i * BLOCK]; }
-#endif
-};
-// LDS map of one 64-lane block: [kinematics cache | stage | active-set factors]
-constexpr int KIN_DOUBLES = wbc::KIN_N * BLOCK;
-constexpr int STAGE_DOUBLES = wbc::ST_N * BLOCK;
-constexpr int SHQ_DOUBLES = (sizeof(wbc::QuadShared) * QROBOTS + 7) / 8;
-// Measured on MI355X (profiles/r01/variants.md): parking the stage in LDS does not beat the
-// compiler's own register/AGPR allocation at one wave per SIMD, so the product build keeps it in
-// registers and lets the active-set block alias the (dead by then) kinematics arena: 24.5 KB/block.
-#ifndef WBC_STAGE_IN_LDS
-#define WBC_STAGE_IN_LDS 0
-#endif
-
-template <int KIND>
-__global__ void __launch_bounds__(BLOCK)
-wbc_quad_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld,
-                const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
-                const uint8_t* __restrict__ mask, const double* __restrict__ mu,
-                const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
-                int32_t* __restrict__ status, StatsDev* __restrict__ stats, double* __restrict__ vdot) {
-#if WBC_STAGE_IN_LDS
-  __shared__ double arena[KIN_DOUBLES + STAGE_DOUBLES + SHQ_DOUBLES];
-  StageLds stage(arena + KIN_DOUBLES + threadIdx.x);
-  wbc::QuadShared* shq = reinterpret_cast<wbc::QuadShared*>(arena + KIN_DOUBLES + STAGE_DOUBLES);
-#else
-  static_assert(SHQ_DOUBLES <= KIN_DOUBLES, "active-set block must fit the kinematics arena it aliases");
-  __shared__ double arena[KIN_DOUBLES];
-  wbc::StageReg<double> stage;
-  wbc::QuadShared* shq = reinterpret_cast<wbc::QuadShared*>(arena);
-#endif
-  LegKinLds kin{arena + threadIdx.x};
-  const int slot = threadIdx.x >> 2;
-  const int i = blockIdx.x * QROBOTS + slot;
-  const bool live = i < n;
-  const int ii = live ? i : (n - 1);
-  // The model table is indexed per LANE (leg = lane & 3).  Read from one global copy that is ~50
-  // dependent vector loads which all 256 CUs issue against the same 14 cache lines at the same
-  // time: measured 18 us of the 78 us tick at N = 4096 (hot-line contention; profiles/r01/cuts.md).
-  // Instead: one batched cooperative copy into LDS from a PER-BLOCK replica (MODEL_REPLICAS copies
-  // in HBM, 2 KB apart), so concurrent blocks hit different lines/channels.
-  __shared__ double mbuf[MODEL_PAD_WORDS];
-  {
-    const double* src = reinterpret_cast<const double*>(mp) + (size_t)(blockIdx.x % MODEL_REPLICAS) * MODEL_PAD_WORDS;
-    double t[MODEL_PAD_WORDS / BLOCK];
-#pragma unroll
-    for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) t[j] = src[j * BLOCK + threadIdx.x];
-#pragma unroll
-    for (int j = 0; j < MODEL_PAD_WORDS / BLOCK; j++) mbuf[j * BLOCK + threadIdx.x] = t[j];
-  }
-  const wbc::ModelC& m = *reinterpret_cast<const wbc::ModelC*>(mbuf);
-  const wbc::ParamsC& P = *pp;
-  QuadDev qo;
-  // Cooperative input staging: all 91 rows x 16 robots of this block are fetched by 23 independent,
-  // 128-B-coalesced loads per lane (one HBM latency for the whole tick) and parked in LDS.  Left to
-  // itself the compiler drip-feeds the ~46 rows a lane needs (load, wait, spill; profiles/r01).
-  __shared__ double inbuf[NIN * QROBOTS];
-  {
-    constexpr int PER_LANE = (NIN * QROBOTS + BLOCK - 1) / BLOCK;
-    double tmp[PER_LANE];
-    const int r0 = blockIdx.x * QROBOTS;
-#pragma unroll
-    for (int j = 0; j < PER_LANE; j++) {
-      const int idx = j * BLOCK + threadIdx.x;
-      const int row = idx / QROBOTS, sl = idx % QROBOTS;
-      const int rob = min(r0 + sl, n - 1);
-      const double* src = row < 19 ? q + (size_t)row * ld : (row < 37 ? v + (size_t)(row - 19) * ld : tg + (size_t)(row - 37) * ld);
-      tmp[j] = (idx < NIN * QROBOTS) ? src[rob] : 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < PER_LANE; j++) {
-      const int idx = j * BLOCK + threadIdx.x;
-      if (idx < NIN * QROBOTS) inbuf[idx] = tmp[j];
-    }
-    __syncthreads();
-  }
-  auto in = [&](int r) -> double { return inbuf[r * QROBOTS + slot]; };
-  double tsum = 0.0, tmax = 0.0, errv = 0.0;
-  auto ot = [&](int k, double x) {
-    if (live) tau[(size_t)k * ld + ii] = x;
-    tsum += fabs(x);
-    tmax = fmax(tmax, fabs(x));
-  };
-  const bool lead = qo.l == 0;
-  auto om = [&](int k, double x) {   // rows 0..3: metrics (lead lane), rows 4..21: generalized accelerations
-    if (k >= 4) {
-      if (live && vdot && (k >= 10 || lead)) vdot[(size_t)(k - 4) * ld + ii] = x;   // base rows are replicated: lead writes
-      return;
-    }
-    if (live && lead && met) met[(size_t)k * ld + ii] = x;
-    if (k == 1) errv = x;
-  };
-  const unsigned mk = mask[ii] & 0xF;
-  const double mui = mu ? mu[ii] : P.mu;
-  const double msi = ms ? ms[ii] : 1.0;
-  int iters = 0;
-  const int st = wbc::quad_tick<QuadDev, KIND>(m, P, qo, in, mk, mui, msi, kin, stage, shq[slot], ot, om, &iters);
-  WBC_STAMP(14);
-  if (live && lead && status) status[ii] = st;
-  if (stats) {
-    stats += blockIdx.x & (STAT_SLOTS - 1);
-    const double lv = (live && lead) ? 1.0 : 0.0, la = live ? 1.0 : 0.0;
-    double a = wave_sum(lv), b = wave_sum((live && lead && st != 0) ? 1.0 : 0.0), c = wave_sum(lv * iters);
-    double d = wave_sum(la * tsum), e = wave_max(la * tmax), f = wave_sum(lv * errv);
-    unsigned long long bal[16];
-    for (int k = 0; k < 16; k++) bal[k] = __ballot(live && lead && mk == (unsigned)k);
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd(&stats->ticks, a);
-      if (b != 0.0) atomicAdd(&stats->status_nonzero, b);
-      atomicAdd(&stats->iters_sum, c);
-      atomicAdd(&stats->tau_abs_sum, d);
-      atomicMax(&stats->tau_abs_max_bits, (unsigned long long)__double_as_longlong(e));
-      atomicAdd(&stats->err_sum, f);
-      for (int k = 0; k < 16; k++)
-        if (bal[k]) atomicAdd(&stats->mask_count[k], (double)__popcll(bal[k]));
-    }
-  }
-}
+static_assert(sizeof(wbc::ModelC) <= MODEL_PAD_WORDS * 8 && MODEL_PAD_WORDS % 64 == 0, "model padding");
 
 // ---------------------------------------------------------------- v4: 16 lanes (one DPP row) per robot
 // Static-lane broadcasts are ONE v_mov_b64_dpp row_newbcast (gfx90a+ DP-ALU DPP); reductions over the
@@ -420,12 +139,6 @@ struct HexDev {
     x |= dppi<0x124>(x);
     return x != 0;
   }
-  __device__ __forceinline__ void argmin16(double& v, int& i) const {
-    QuadDev::amin(v, i, dpp<0xB1>(v), dppi<0xB1>(i));
-    QuadDev::amin(v, i, dpp<0x4E>(v), dppi<0x4E>(i));
-    QuadDev::amin(v, i, dpp<0x128>(v), dppi<0x128>(i));
-    QuadDev::amin(v, i, dpp<0x124>(v), dppi<0x124>(i));
-  }
   __device__ __forceinline__ bool wave_all(bool b) const { return __all(b); }
   __device__ __forceinline__ int wave_max_int(int x) const {
     int m = 0;
@@ -474,7 +187,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   const bool live = i < n;
   const int ii = live ? i : (n - 1);
   // Prologue: EVERY global load of the tick is issued here, unconditionally (clamped indices, no divergent
-  // guards), before the single wait: model table (per-block replica, see wbc_quad_kernel), the 91 x 4 input
+  // guards), before the single wait: model table (per-block replica: concurrent blocks hit different lines / channels), the 91 x 4 input
   // words, and the per-robot mask / mu / mass scale -- one memory round trip instead of two (profiles/r01/hex_cuts.md).
   const double* msrc = reinterpret_cast<const double*>(mp) + (size_t)(blockIdx.x % MODEL_REPLICAS) * MODEL_PAD_WORDS;
   double t[MPER], tmp[PER_LANE];
@@ -590,7 +303,7 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* _
 #pragma unroll
     for (int r = h; r < NST; r += 16)
       inbuf[r * HROBOTS + slot] = (r < 19) ? q[(size_t)r * ld + ii] : v[(size_t)(r - 19) * ld + ii];
-    for (int r = h; r < 18; r += 16) vdbuf[slot * 18 + r] = vdot[(size_t)r * ld + ii];
+    for (int r = h; r < 18; r += 16) vdbuf[slot * 18 + r] = 0.0;   // vdot is an OUTPUT: never read from the caller
   }
   if (lead) {
     robuf[slot * 4 + 0] = time[ii];
@@ -760,7 +473,7 @@ __global__ void wbc_advance_time_kernel(int n, double dt, double* __restrict__ t
 struct wbc_handle_s {
   int kind, max_batch, device, variant;
   int last_variant;  // kernel used by the most recent launch (1 lane, 2 quad, 3 hex)
-  bool torque_box, lane_only;
+  bool torque_box;
   uint32_t flags;
   hipStream_t stream;
   bool own_stream;
@@ -769,6 +482,7 @@ struct wbc_handle_s {
   StatsDev* d_stats;
   StatsDev* h_stats;  // pinned, device-mapped: the reduce kernel writes the totals straight into host memory
   hipEvent_t ev0, ev1;
+  std::vector<hipEvent_t> evs;  // per-launch events of wbc_time_steps_each (grown on demand, outside any timed region)
   // staging buffers for WBC_HOST_PTRS
   double* d_vdot;  // optional [18][ld] output of the generalized accelerations (wbc_set_vdot_output)
   double *s_q, *s_v, *s_tg, *s_mu, *s_ms, *s_tau, *s_met;
@@ -777,6 +491,8 @@ struct wbc_handle_s {
 };
 
 extern "C" int wbc_traj_raw_(wbc_traj t, wbc::TrajDev* out);   // wbc_traj.hip (internal)
+// internal: wbc_traj.hip reports its failures through the same thread-local buffer wbc_last_error() returns
+extern "C" void wbc_set_error_(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg ? msg : ""); }
 
 extern "C" {
 
@@ -815,37 +531,41 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
     return misuse("wbc_create: mu, eps2, w_body, w_foot and tau_max must be positive");
   HIP_TRY(hipSetDevice(device));
   wbc_handle h = new wbc_handle_s();
-  memset(h, 0, sizeof *h);
   h->kind = kind; h->max_batch = max_batch; h->device = device; h->flags = flags;
   h->variant = 0;
   h->torque_box = P.tau_max < 1e300;
-  h->lane_only = false;           // every law and the optional torque box run on the 16-lane kernel
-  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-  h->own_stream = true;
-  HIP_TRY(hipMalloc(&h->d_model, (size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8));
-  HIP_TRY(hipMalloc(&h->d_params, sizeof P));
-  HIP_TRY(hipMalloc(&h->d_stats, sizeof(StatsDev) * (STAT_SLOTS + 1)));
-  {
-    // MODEL_REPLICAS padded copies (the lane-per-robot kernel reads replica 0 through a ModelC*)
-    char* rep = new char[(size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8]();
-    for (int r = 0; r < MODEL_REPLICAS; r++) memcpy(rep + (size_t)r * MODEL_PAD_WORDS * 8, &m, sizeof m);
-    hipError_t e = hipMemcpy(h->d_model, rep, (size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8, hipMemcpyHostToDevice);
-    delete[] rep;
-    if (e != hipSuccess) return fail("hipMemcpy(model replicas)", e);
-  }
-  HIP_TRY(hipMemcpy(h->d_params, &P, sizeof P, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemset(h->d_stats, 0, sizeof(StatsDev) * (STAT_SLOTS + 1)));
-  HIP_TRY(hipHostMalloc(&h->h_stats, sizeof(StatsDev), hipHostMallocMapped));
-  HIP_TRY(hipEventCreate(&h->ev0));
-  HIP_TRY(hipEventCreate(&h->ev1));
-  if (flags & WBC_HOST_PTRS) {
-    size_t nb = (size_t)max_batch;
-    HIP_TRY(hipMalloc(&h->s_q, 19 * nb * 8)); HIP_TRY(hipMalloc(&h->s_v, 18 * nb * 8));
-    HIP_TRY(hipMalloc(&h->s_tg, 54 * nb * 8)); HIP_TRY(hipMalloc(&h->s_mu, nb * 8));
-    HIP_TRY(hipMalloc(&h->s_ms, nb * 8)); HIP_TRY(hipMalloc(&h->s_tau, 12 * nb * 8));
-    HIP_TRY(hipMalloc(&h->s_met, 4 * nb * 8)); HIP_TRY(hipMalloc(&h->s_mask, nb));
-    HIP_TRY(hipMalloc(&h->s_status, nb * 4));
-  }
+  // every allocation below is released by wbc_destroy on failure (null members are skipped)
+  auto build = [&]() -> int {
+    HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+    HIP_TRY(hipMalloc(&h->d_model, (size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8));
+    HIP_TRY(hipMalloc(&h->d_params, sizeof P));
+    HIP_TRY(hipMalloc(&h->d_stats, sizeof(StatsDev) * (STAT_SLOTS + 1)));
+    {
+      // MODEL_REPLICAS padded copies: concurrent workgroups read different lines / channels
+      char* rep = new char[(size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8]();
+      for (int r = 0; r < MODEL_REPLICAS; r++) memcpy(rep + (size_t)r * MODEL_PAD_WORDS * 8, &m, sizeof m);
+      hipError_t e = hipMemcpy(h->d_model, rep, (size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8, hipMemcpyHostToDevice);
+      delete[] rep;
+      if (e != hipSuccess) return fail("hipMemcpy(model replicas)", e);
+    }
+    HIP_TRY(hipMemcpy(h->d_params, &P, sizeof P, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(h->d_stats, 0, sizeof(StatsDev) * (STAT_SLOTS + 1)));
+    HIP_TRY(hipHostMalloc(&h->h_stats, sizeof(StatsDev), hipHostMallocMapped));
+    HIP_TRY(hipEventCreate(&h->ev0));
+    HIP_TRY(hipEventCreate(&h->ev1));
+    if (flags & WBC_HOST_PTRS) {
+      size_t nb = (size_t)max_batch;
+      HIP_TRY(hipMalloc(&h->s_q, 19 * nb * 8)); HIP_TRY(hipMalloc(&h->s_v, 18 * nb * 8));
+      HIP_TRY(hipMalloc(&h->s_tg, 54 * nb * 8)); HIP_TRY(hipMalloc(&h->s_mu, nb * 8));
+      HIP_TRY(hipMalloc(&h->s_ms, nb * 8)); HIP_TRY(hipMalloc(&h->s_tau, 12 * nb * 8));
+      HIP_TRY(hipMalloc(&h->s_met, 4 * nb * 8)); HIP_TRY(hipMalloc(&h->s_mask, nb));
+      HIP_TRY(hipMalloc(&h->s_status, nb * 4));
+    }
+    return 0;
+  };
+  const int rc = build();
+  if (rc) { wbc_destroy(h); return rc; }   // g_err keeps the message of the failed call
   *out = h;
   return 0;
 }
@@ -853,14 +573,15 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
 int wbc_destroy(wbc_handle h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
-  (void)hipStreamSynchronize(h->stream);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->d_model, h->d_params, h->d_stats, h->s_q, h->s_v, h->s_tg, h->s_mu, h->s_ms,
                   h->s_tau, h->s_met, h->s_mask, h->s_status};
-  for (void* b : bufs) (void)hipFree(b);
-  (void)hipHostFree(h->h_stats);
-  (void)hipEventDestroy(h->ev0);
-  (void)hipEventDestroy(h->ev1);
-  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (h->h_stats) (void)hipHostFree(h->h_stats);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (hipEvent_t e : h->evs) (void)hipEventDestroy(e);
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
 }
@@ -876,77 +597,33 @@ int wbc_set_stream(wbc_handle h, void* hip_stream) {
   return 0;
 }
 
-// variant 0 = auto.  Measured on MI355X (profiles/r01/hex_sweep.md): the 16-lane kernel wins at every batch
-// size for MPTC/PC; for the (active-set-bound) ID law it wins while its n/4 wavefronts fit four per SIMD of
-// the 256 CUs (N <= 16384), beyond that the quad kernel's lower total instruction count wins.  The torque box and the CLF law exist on the
-// lane-per-robot kernel only.
-static int pick_variant(const wbc_handle_s* h, int n) {
-  if (h->variant) return h->variant;
-  if (h->lane_only) return 1;
-  if (h->kind != WBC_KIND_ID || h->torque_box) return 3;   // MPTC, PC, CLF, torque box: 16-lane (or lane-per-robot) only
-  return (n + 3) / 4 <= 4096 ? 3 : 2;
-}
+// One product kernel family (16 lanes per robot) for every law, batch size and option; the variant number (3) is
+// kept in the ABI for compatibility with round-1 callers.
+static int pick_variant(const wbc_handle_s*, int) { return 3; }
 
 static int launch(wbc_handle h, int n, int ld, const double* q, const double* v, const double* tg,
                   const uint8_t* mask, const double* mu, const double* ms, double* tau, double* met,
                   int32_t* status) {
-  // variant 0 = auto: the quad kernel (4 lanes per robot) unless the optional torque box is on,
-  // which only the lane-per-robot kernel implements.
-  const int var = pick_variant(h, n);
-  h->last_variant = var;
-  const bool hex = (var == 3), quad = (var == 2);
-  dim3 block(BLOCK);
+  h->last_variant = 3;
   StatsDev* d_stats = getenv("WBC_NO_STATS") ? nullptr : h->d_stats;  // diagnostic switch
-#define WBC_LAUNCH(KERNEL, GRID)                                                                              \
-  do {                                                                                                       \
-    switch (h->kind) {                                                                                       \
-      case WBC_KIND_ID:                                                                                      \
-        hipLaunchKernelGGL(KERNEL<wbc::KIND_ID>, GRID, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg, \
-                           mask, mu, ms, tau, met, status, d_stats, h->d_vdot);                                         \
-        break;                                                                                               \
-      case WBC_KIND_MPTC:                                                                                    \
-        hipLaunchKernelGGL(KERNEL<wbc::KIND_MPTC>, GRID, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v,   \
-                           tg, mask, mu, ms, tau, met, status, d_stats, h->d_vdot);                                     \
-        break;                                                                                               \
-      default:                                                                                               \
-        hipLaunchKernelGGL(KERNEL<wbc::KIND_PC>, GRID, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg, \
-                           mask, mu, ms, tau, met, status, d_stats, h->d_vdot);                                         \
-    }                                                                                                        \
-  } while (0)
-#define WBC_LAUNCH_CLF(KERNEL, GRID)                                                                         \
-  hipLaunchKernelGGL(KERNEL<wbc::KIND_CLF>, GRID, block, 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg,      \
-                     mask, mu, ms, tau, met, status, d_stats, h->d_vdot)
-  if (hex) {
-    dim3 grid((n + HROBOTS - 1) / HROBOTS);
+  dim3 grid((n + HROBOTS - 1) / HROBOTS);
 #define WBC_HEX_ARGS grid, dim3(HEX_BLOCK), 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg, mask, mu, ms, tau, met, status, d_stats, h->d_vdot
-    if (h->torque_box) {   // second constraint slot per lane: |tau_j| <= tau_max (wbc_hex.hpp)
-      switch (h->kind) {
-        case WBC_KIND_ID: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_ID, true>), WBC_HEX_ARGS); break;
-        case WBC_KIND_MPTC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_MPTC, true>), WBC_HEX_ARGS); break;
-        case WBC_KIND_PC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_PC, true>), WBC_HEX_ARGS); break;
-        default: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_CLF, true>), WBC_HEX_ARGS);
-      }
-    } else {
-      switch (h->kind) {
-        case WBC_KIND_ID: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_ID, false>), WBC_HEX_ARGS); break;
-        case WBC_KIND_MPTC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_MPTC, false>), WBC_HEX_ARGS); break;
-        case WBC_KIND_PC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_PC, false>), WBC_HEX_ARGS); break;
-        default: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_CLF, false>), WBC_HEX_ARGS);
-      }
+  if (h->torque_box) {   // second constraint slot per lane: |tau_j| <= tau_max (wbc_hex.hpp)
+    switch (h->kind) {
+      case WBC_KIND_ID: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_ID, true>), WBC_HEX_ARGS); break;
+      case WBC_KIND_MPTC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_MPTC, true>), WBC_HEX_ARGS); break;
+      case WBC_KIND_PC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_PC, true>), WBC_HEX_ARGS); break;
+      default: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_CLF, true>), WBC_HEX_ARGS);
     }
-#undef WBC_HEX_ARGS
-  } else if (quad) {
-    dim3 grid((n + QROBOTS - 1) / QROBOTS);
-    WBC_LAUNCH(wbc_quad_kernel, grid);
-  } else if (h->kind == WBC_KIND_CLF) {
-    dim3 grid((n + BLOCK - 1) / BLOCK);
-    WBC_LAUNCH_CLF(wbc_tick_kernel, grid);
   } else {
-    dim3 grid((n + BLOCK - 1) / BLOCK);
-    WBC_LAUNCH(wbc_tick_kernel, grid);
+    switch (h->kind) {
+      case WBC_KIND_ID: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_ID, false>), WBC_HEX_ARGS); break;
+      case WBC_KIND_MPTC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_MPTC, false>), WBC_HEX_ARGS); break;
+      case WBC_KIND_PC: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_PC, false>), WBC_HEX_ARGS); break;
+      default: hipLaunchKernelGGL((wbc_hex_kernel<wbc::KIND_CLF, false>), WBC_HEX_ARGS);
+    }
   }
-#undef WBC_LAUNCH
-#undef WBC_LAUNCH_CLF
+#undef WBC_HEX_ARGS
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1015,6 +692,31 @@ int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, cons
   return 0;
 }
 
+int wbc_time_steps_each(wbc_handle h, int steps, int n, int ld, const double* q, const double* v,
+                        const double* targets, const uint8_t* contact_mask, const double* mu,
+                        const double* mass_scale, double* tau, double* metrics, int32_t* status,
+                        float* ms_each) {
+  int rc = check_step_args(h, n, ld, q, v, targets, contact_mask, tau);
+  if (rc) return rc;
+  if (steps <= 0 || !ms_each) return misuse("wbc_time_steps_each: steps must be positive and ms_each non-null");
+  if (h->flags & WBC_HOST_PTRS) return misuse("wbc_time_steps_each: needs a WBC_DEVICE_PTRS handle (inputs resident in HBM)");
+  HIP_TRY(hipSetDevice(h->device));
+  while ((int)h->evs.size() < steps + 1) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    h->evs.push_back(e);
+  }
+  HIP_TRY(hipEventRecord(h->evs[0], h->stream));
+  for (int s = 0; s < steps; s++) {
+    rc = launch(h, n, ld, q, v, targets, contact_mask, mu, mass_scale, tau, metrics, status);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(h->evs[s + 1], h->stream));
+  }
+  HIP_TRY(hipEventSynchronize(h->evs[steps]));
+  for (int s = 0; s < steps; s++) HIP_TRY(hipEventElapsedTime(&ms_each[s], h->evs[s], h->evs[s + 1]));
+  return 0;
+}
+
 int wbc_stats_get(wbc_handle h, wbc_stats* out) {
   if (!h || !out) return misuse("wbc_stats_get: null argument");
   HIP_TRY(hipSetDevice(h->device));
@@ -1078,8 +780,8 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
   if (h->flags & WBC_HOST_PTRS) return misuse("wbc_rollout: needs a WBC_DEVICE_PTRS handle");
   if (steps == 0 || n == 0) return 0;
   HIP_TRY(hipSetDevice(h->device));
-  if (pick_variant(h, n) == 3) {
-    // 16-lane mapping: the whole rollout is ONE persistent launch (wbc_hex_rollout_kernel)
+  {
+    // the whole rollout is ONE persistent launch per <= 1024 ticks (wbc_hex_rollout_kernel)
     wbc::TrajDev T;
     if (wbc_traj_raw_(traj, &T)) return misuse("wbc_rollout: bad trajectory handle");
     h->last_variant = 3;
@@ -1105,28 +807,12 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
     HIP_TRY(hipGetLastError());
     return 0;
   }
-  // other mappings: one launch per stage (lookup, tick, forward step, time)
-  double* saved = h->d_vdot;
-  h->d_vdot = vdot;
-  for (int s = 0; s < steps && rc == 0; s++) {
-    rc = wbc_traj_lookup(traj, (void*)h->stream, n, ld, time, targets, contact_mask);
-    if (rc) { snprintf(g_err, sizeof g_err, "wbc_rollout: wbc_traj_lookup failed (%d)", rc); break; }
-    rc = launch(h, n, ld, q, v, targets, contact_mask, mu, mass_scale, tau, metrics, status);
-    if (rc) break;
-    hipLaunchKernelGGL(wbc_integrate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, ld, dt, q, v, vdot);
-    hipLaunchKernelGGL(wbc_advance_time_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, dt, time);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) rc = fail("wbc_rollout launch", e);
-  }
-  h->d_vdot = saved;
-  return rc;
 }
 
 int wbc_set_variant(wbc_handle h, int variant) {
   if (!h) return misuse("wbc_set_variant: null handle");
-  if (variant < 0 || variant > 3) return misuse("wbc_set_variant: 0 = auto, 1 = lane-per-robot, 2 = quad-per-robot, 3 = 16 lanes per robot");
-  if (variant == 2 && (h->kind == WBC_KIND_CLF || h->torque_box))
-    return misuse("wbc_set_variant: the CLF law and the torque box run on the 16-lane or the lane-per-robot kernel");
+  if (variant != 0 && variant != 3)
+    return misuse("wbc_set_variant: 0 = auto or 3 = 16 lanes per robot (the lane- and quad-per-robot kernels of round 1 are retired)");
   h->variant = variant;
   return 0;
 }
@@ -1139,26 +825,20 @@ int wbc_variant_for(wbc_handle h, int n) {
 int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads) {
   if (!h) return misuse("wbc_kernel_info: null handle");
   hipFuncAttributes a;
-  const int var = h->last_variant ? h->last_variant : pick_variant(h, h->max_batch);
-  const bool quad = (var == 2);
   const void* fn;
-  if (var == 3 && h->torque_box)
+  if (h->torque_box)
     fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID, true>
        : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_kernel<wbc::KIND_MPTC, true>
        : h->kind == WBC_KIND_PC ? (const void*)wbc_hex_kernel<wbc::KIND_PC, true> : (const void*)wbc_hex_kernel<wbc::KIND_CLF, true>;
-  else if (var == 3) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID>
-               : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_kernel<wbc::KIND_MPTC>
-               : h->kind == WBC_KIND_PC ? (const void*)wbc_hex_kernel<wbc::KIND_PC> : (const void*)wbc_hex_kernel<wbc::KIND_CLF>;
-  else if (quad) fn = h->kind == WBC_KIND_ID ? (const void*)wbc_quad_kernel<wbc::KIND_ID>
-               : h->kind == WBC_KIND_MPTC ? (const void*)wbc_quad_kernel<wbc::KIND_MPTC> : (const void*)wbc_quad_kernel<wbc::KIND_PC>;
-  else fn = h->kind == WBC_KIND_ID ? (const void*)wbc_tick_kernel<wbc::KIND_ID>
-          : h->kind == WBC_KIND_MPTC ? (const void*)wbc_tick_kernel<wbc::KIND_MPTC>
-          : h->kind == WBC_KIND_PC ? (const void*)wbc_tick_kernel<wbc::KIND_PC> : (const void*)wbc_tick_kernel<wbc::KIND_CLF>;
+  else
+    fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID>
+       : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_kernel<wbc::KIND_MPTC>
+       : h->kind == WBC_KIND_PC ? (const void*)wbc_hex_kernel<wbc::KIND_PC> : (const void*)wbc_hex_kernel<wbc::KIND_CLF>;
   HIP_TRY(hipFuncGetAttributes(&a, fn));
   if (num_vgpr) *num_vgpr = a.numRegs;
   if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;
   if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;
-  if (block_threads) *block_threads = (var == 3) ? HEX_BLOCK : BLOCK;
+  if (block_threads) *block_threads = HEX_BLOCK;
   return 0;
 }
 

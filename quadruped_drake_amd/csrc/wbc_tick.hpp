@@ -1215,6 +1215,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
   if (status == ST_SINGULAR) {
     for (int k = 0; k < 12; k++) out_tau(k, T(0.0));
     out_met(0, T(0.0)); out_met(1, met_err); out_met(2, T(0.0)); out_met(3, T(0.0));
+    for (int k = 0; k < 18; k++) out_met(4 + k, T(0.0));   // defined accelerations with the zero torques
     *iters_out = 0;
     return status;
   }
@@ -1291,7 +1292,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       T sab = ab0[i];
       for (int c = 0; c < NZ; c++) sab = sab + B[i][c] * z[c];
       ab[i] = sab;
-      out_met(4 + i, sab);
+      out_met(4 + i, (status == ST_SINGULAR) ? T(0.0) : sab);
     }
     for (int l = 0; l < 4; l++) {
       bool ctl = (mask >> l) & 1;
@@ -1299,7 +1300,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       cross(ab, rr, t);
       for (int i = 0; i < 3; i++) y[i] = (ctl ? bc[l][i] : z[3 * l + i]) - (ab[3 + i] + t[i]);
       rotv(D[l].Ji, y, vd);
-      for (int k = 0; k < 3; k++) out_met(4 + 6 + m.q_perm[3 * l + k], vd[k]);
+      for (int k = 0; k < 3; k++) out_met(4 + 6 + m.q_perm[3 * l + k], (status == ST_SINGULAR) ? T(0.0) : vd[k]);
     }
   }
   // primal residual: worst friction / torque-box violation

@@ -10,9 +10,17 @@
 #include "../../include/wbc.h"
 #include "wbc_traj_dev.hpp"
 
+// the one thread-local message buffer behind wbc_last_error() (defined in wbc_kernels.hip)
+extern "C" void wbc_set_error_(const char* msg);
+
 namespace {
-thread_local char g_terr[256] = "";
-int tfail(const char* what, hipError_t e) { snprintf(g_terr, sizeof g_terr, "%s: %s", what, hipGetErrorString(e)); return -2; }
+int tfail(const char* what, hipError_t e) {
+  char b[256];
+  snprintf(b, sizeof b, "%s: %s", what, hipGetErrorString(e));
+  wbc_set_error_(b);
+  return -2;
+}
+int tmisuse(const char* what) { wbc_set_error_(what); return -1; }
 #define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return tfail(#x, e_); } while (0)
 
 // lcm_types/trunklcm/trunk_state_t.py:123-133: hash = rotl1(0xbd03c56c9649d0b6)
@@ -91,24 +99,31 @@ int wbc_trunk_state_to_targets(const wbc_trunk_state* s, double* t, uint8_t* con
 
 int wbc_traj_create(int device, int K, const double* timestamps, const double* targets, const uint8_t* masks,
                     const double* standing_targets54, uint8_t standing_mask, double wait_time, wbc_traj* out) {
-  if (!out || K < 0 || (K > 0 && (!timestamps || !targets || !masks)) || !standing_targets54) return -1;
+  if (!out || K < 0 || (K > 0 && (!timestamps || !targets || !masks)) || !standing_targets54)
+    return tmisuse("wbc_traj_create: bad argument");
   for (int i = 1; i < K; i++)
-    if (!(timestamps[i] >= timestamps[i - 1])) return -1;  // must be non-decreasing
+    if (!(timestamps[i] >= timestamps[i - 1])) return tmisuse("wbc_traj_create: timestamps must be non-decreasing");
   HIP_TRY(hipSetDevice(device));
   wbc_traj t = new wbc_traj_s();
   memset(t, 0, sizeof *t);
   t->device = device; t->K = K; t->wait_time = wait_time; t->standing_mask = standing_mask;
   const size_t kk = K > 0 ? K : 1;
-  HIP_TRY(hipMalloc(&t->d_ts, kk * 8));
-  HIP_TRY(hipMalloc(&t->d_table, kk * 54 * 8));
-  HIP_TRY(hipMalloc(&t->d_masks, kk));
-  HIP_TRY(hipMalloc(&t->d_standing, 54 * 8));
-  if (K > 0) {
-    HIP_TRY(hipMemcpy(t->d_ts, timestamps, (size_t)K * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t->d_table, targets, (size_t)K * 54 * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(t->d_masks, masks, (size_t)K, hipMemcpyHostToDevice));
-  }
-  HIP_TRY(hipMemcpy(t->d_standing, standing_targets54, 54 * 8, hipMemcpyHostToDevice));
+  // any failure below releases what was already allocated (hipFree(nullptr) is a no-op)
+  auto build = [&]() -> int {
+    HIP_TRY(hipMalloc(&t->d_ts, kk * 8));
+    HIP_TRY(hipMalloc(&t->d_table, kk * 54 * 8));
+    HIP_TRY(hipMalloc(&t->d_masks, kk));
+    HIP_TRY(hipMalloc(&t->d_standing, 54 * 8));
+    if (K > 0) {
+      HIP_TRY(hipMemcpy(t->d_ts, timestamps, (size_t)K * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(t->d_table, targets, (size_t)K * 54 * 8, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(t->d_masks, masks, (size_t)K, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpy(t->d_standing, standing_targets54, 54 * 8, hipMemcpyHostToDevice));
+    return 0;
+  };
+  const int rc = build();
+  if (rc) { wbc_traj_destroy(t); return rc; }
   *out = t;
   return 0;
 }
@@ -123,7 +138,7 @@ int wbc_traj_destroy(wbc_traj t) {
 
 int wbc_traj_lookup(wbc_traj t, void* hip_stream, int n, int ld, const double* time, double* targets,
                     uint8_t* contact_mask) {
-  if (!t || n < 0 || (n > 0 && (ld < n || !time || !targets || !contact_mask))) return -1;
+  if (!t || n < 0 || (n > 0 && (ld < n || !time || !targets || !contact_mask))) return tmisuse("wbc_traj_lookup: bad argument");
   if (n == 0) return 0;
   HIP_TRY(hipSetDevice(t->device));
   wbc::TrajDev T{t->K, t->wait_time, t->d_ts, t->d_table, t->d_masks, t->d_standing, t->standing_mask};

@@ -43,16 +43,22 @@ def unpack(s, m):
     return out
 
 
-def all_reduce_stats(stats, device=None):
-    """Reduce a wbc_stats dict over the default process group (no-op without one)."""
+def all_gather_stats(stats, device=None):
+    """ONE collective: gather every rank's 22-double vector, reduce (sum / max) locally.
+    Returns (reduced dict, per-rank list of dicts, world size seen by the process group)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return dict(stats)
+        return dict(stats), [dict(stats)], 1
     s, m = pack(stats)
-    # ONE collective: gather every rank's 22-double vector, reduce (sum / max) locally
     t = torch.tensor(np.concatenate([s, m]), dtype=torch.float64, device=device)
     parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, t)
     a = torch.stack(parts).cpu().numpy()
-    return unpack(a[:, :len(s)].sum(0), a[:, len(s):].max(0))
+    per_rank = [unpack(a[r, :len(s)], a[r, len(s):]) for r in range(a.shape[0])]
+    return unpack(a[:, :len(s)].sum(0), a[:, len(s):].max(0)), per_rank, dist.get_world_size()
+
+
+def all_reduce_stats(stats, device=None):
+    """Reduce a wbc_stats dict over the default process group (no-op without one)."""
+    return all_gather_stats(stats, device)[0]

@@ -47,8 +47,7 @@ class TrunkTrajectory:
         rc = self._L.wbc_traj_create(device, ts.size, ts.ctypes.data_as(_lib.c_double_p), tg.ctypes.data_as(_lib.c_double_p),
                                      mk.ctypes.data_as(_lib.c_u8_p), st.ctypes.data_as(_lib.c_double_p), standing_mask,
                                      float(wait_time), C.byref(h))
-        if rc != 0:
-            raise _lib.WbcError("wbc_traj_create failed (rc=%d): timestamps must be non-decreasing, a GPU is required" % rc)
+        _lib.check(rc)   # message from wbc_last_error(): bad argument / non-decreasing timestamps / the HIP failure
         self._h = h
 
     @classmethod
@@ -60,11 +59,20 @@ class TrunkTrajectory:
     def lookup(self, time, out=None):
         """time: CUDA float64 tensor [n] -> (targets [54, n], contact_mask [n]) on the current stream."""
         import torch
+        if not (isinstance(time, torch.Tensor) and time.is_cuda and time.dtype == torch.float64 and time.is_contiguous()
+                and time.dim() == 1 and time.device.index == self.device):
+            raise ValueError("time: expected a contiguous float64 CUDA tensor [n] on device %d" % self.device)
         n = int(time.shape[0])
+        if out is not None:
+            tg, mk = out
+            ok = (tg.is_cuda and tg.dtype == torch.float64 and tg.is_contiguous() and tuple(tg.shape) == (54, n) and
+                  mk.is_cuda and mk.dtype == torch.uint8 and mk.is_contiguous() and tuple(mk.shape) == (n,))
+            if not ok:
+                raise ValueError("out: expected (float64 [54, n], uint8 [n]) contiguous CUDA tensors")
         if out is None:
             dev = time.device
             out = (torch.empty((54, n), dtype=torch.float64, device=dev), torch.empty((n,), dtype=torch.uint8, device=dev))
-        stream = torch.cuda.current_stream().cuda_stream
+        stream = torch.cuda.current_stream(self.device).cuda_stream
         _lib.check(self._L.wbc_traj_lookup(self._h, C.c_void_p(stream), n, n, C.c_void_p(time.data_ptr()),
                                            C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr())))
         return out

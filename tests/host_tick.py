@@ -18,7 +18,6 @@ def lib():
         srcs = [os.path.join(_ROOT, "tools", "host_tick.cpp"),
                 os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_tick.hpp"),
                 os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_model.hpp"),
-                os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_quad.hpp"),
                 os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_hex.hpp"),
                 os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_traj_dev.hpp")]
         if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
@@ -33,7 +32,7 @@ def _p(a):
 
 
 def run(kind, flat, q, v, targets, mask, mu=None, mass_scale=None, params12=None, q_perm=None, act_perm=None,
-        quad=False, want_vdot=False, hexv=False):
+        want_vdot=False, hexv=False):
     q, v, targets = (np.ascontiguousarray(a, dtype=np.float64) for a in (q, v, targets))
     mask = np.ascontiguousarray(mask, dtype=np.uint8)
     flat = np.ascontiguousarray(flat, dtype=np.float64)
@@ -48,7 +47,7 @@ def run(kind, flat, q, v, targets, mask, mu=None, mass_scale=None, params12=None
     vdot = np.zeros((18, n)) if want_vdot else None
     lib().host_set_vdot_sink.argtypes = [C.c_void_p]
     lib().host_set_vdot_sink(vdot.ctypes.data_as(C.c_void_p) if want_vdot else None)
-    fn = lib().host_hex_batch if hexv else (lib().host_quad_batch if quad else lib().host_tick_batch)
+    fn = lib().host_hex_batch if hexv else lib().host_tick_batch
     rc = fn(k, _p(flat), _p(pp), qp.ctypes.data_as(_ip) if qp is not None else None,
                                ap.ctypes.data_as(_ip) if ap is not None else None, n, n, _p(q), _p(v),
                                _p(targets), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), _p(mu), _p(ms),

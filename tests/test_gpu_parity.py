@@ -24,14 +24,12 @@ def rel_err(tau, tau_o):
     return np.abs(tau - tau_o).max(0) / np.maximum(np.abs(tau_o).max(0), 1e-3)
 
 
-def gpu_step(kind, model, q, v, tg, mask, mu=None, ms=None, params=None, max_batch=None, variant="auto", **kw):
+def gpu_step(kind, model, q, v, tg, mask, mu=None, ms=None, params=None, max_batch=None, **kw):
     torch = _torch()
     from quadruped_drake_amd import IDController, MPTCController, PCController, CLFController
     cls = {"id": IDController, "mptc": MPTCController, "pc": PCController, "clf": CLFController}[kind]
     n = q.shape[1]
     ctrl = cls(model=model, max_batch=max_batch or n, device=0, params=params, **kw)
-    if not (kind == "clf" and variant == "quad"):       # CLF has no quad kernel: that case runs auto (16-lane)
-        ctrl.set_variant(variant)
     up = lambda x: None if x is None else torch.tensor(np.ascontiguousarray(x), device="cuda:0")
     tau, met, st = ctrl.step(up(q), up(v), up(tg), up(mask), up(mu), up(ms))
     ctrl.sync()
@@ -58,26 +56,22 @@ def test_native_library_is_the_one_loaded():
         assert "libwbc_hip.so" in f.read()
 
 
-@pytest.mark.parametrize("variant", ["hex", "quad", "lane"])
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
-def test_gpu_matches_golden_vectors(path, variant):
+def test_gpu_matches_golden_vectors(path):
     g = load_gold(path)
-    tau, met, st, _ = gpu_step(g["kind"], g["model"], g["q"], g["v"], g["targets"], g["mask"], g["mu"], g["mass_scale"],
-                               variant=variant)
+    tau, met, st, _ = gpu_step(g["kind"], g["model"], g["q"], g["v"], g["targets"], g["mask"], g["mu"], g["mass_scale"])
     assert np.array_equal(st, g["status"])
     assert rel_err(tau, g["tau"]).max() < TOL
     assert np.allclose(met, g["metrics"], rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("variant", ["hex", "quad", "lane"])
 @pytest.mark.parametrize("cfg,kind,n", [(2, "id", 1024), (3, "mptc", 2048), (4, "mptc", 1024), (5, "mptc", 1024), (3, "id", 512),
                                         (3, "pc", 1024), (2, "pc", 256), (3, "clf", 512), (2, "clf", 256)])
-def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n, variant):
+def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n):
     from oracle import oracle_py as orc
     from quadruped_drake_amd import workloads
     b = workloads.make_batch(cfg, n=n)
-    tau, met, st, stats = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"],
-                                   variant=variant)
+    tau, met, st, stats = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
     m = orc.model(b["model"]); p = orc.params(kind)
     tau_o, met_o, st_o = orc.step_batch(kind, m, p, b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
     assert (st == 0).all() and (st_o == 0).all()
@@ -92,13 +86,12 @@ def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n, variant):
     assert stats["mask_count"] == [float((b["mask"] == k).sum()) for k in range(16)]
 
 
-@pytest.mark.parametrize("variant", ["hex", "quad"])
 @pytest.mark.parametrize("n", [1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 200])
-def test_ragged_batch_sizes(n, variant):
+def test_ragged_batch_sizes(n):
     from oracle import oracle_py as orc
     from quadruped_drake_amd import workloads
     b = workloads.make_batch(3, n=n)
-    tau, met, st, _ = gpu_step("mptc", b["model"], b["q"], b["v"], b["targets"], b["mask"], max_batch=256, variant=variant)
+    tau, met, st, _ = gpu_step("mptc", b["model"], b["q"], b["v"], b["targets"], b["mask"], max_batch=256)
     tau_o, _, _ = orc.step_batch("mptc", orc.model(b["model"]), orc.params("mptc"), b["q"], b["v"], b["targets"], b["mask"])
     assert tau.shape == (12, n) and (st == 0).all()
     assert rel_err(tau, tau_o).max() < TOL
@@ -136,15 +129,14 @@ def test_torque_box_friction_and_host_pointer_mode():
     assert rel_err(tau[:, ok], tau_o[:, ok]).max() < TOL
 
 
-@pytest.mark.parametrize("variant", ["hex", "lane"])
 @pytest.mark.parametrize("cfg,kind,tmax", [(3, "mptc", 10.0), (2, "id", 12.0), (3, "clf", 12.0), (3, "pc", 10.0)])
-def test_torque_box_on_both_mappings(cfg, kind, tmax, variant):
+def test_torque_box(cfg, kind, tmax):
     """tau_max < inf: 24 more inequality rows (north star: torque-limit inequalities); device pointers, N = 512."""
     from oracle import oracle_py as orc
     from quadruped_drake_amd import workloads
     b = workloads.make_batch(cfg, n=512)
     tau, met, st, stats = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"],
-                                   params={"tau_max": tmax}, variant=variant)
+                                   params={"tau_max": tmax})
     p = orc.params(kind); p.tau_max = tmax
     tau_o, _, st_o = orc.step_batch(kind, orc.model(b["model"]), p, b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
     assert np.array_equal(st == 0, st_o == 0)
@@ -154,16 +146,29 @@ def test_torque_box_on_both_mappings(cfg, kind, tmax, variant):
     assert rel_err(tau[:, ok], tau_o[:, ok]).max() < TOL
 
 
-def test_joint_and_actuator_permutations():
+@pytest.mark.parametrize("kind,cfg", [("mptc", 3), ("id", 2), ("clf", 3)])
+def test_joint_and_actuator_permutations_against_the_oracle(kind, cfg):
+    """Non-identity q_perm AND act_perm (a breadth-first Drake joint numbering, basic_controller.py:310-313):
+    the caller's q/v rows are permuted, the oracle sees the canonical rows and carries act_perm itself."""
+    from oracle import oracle_py as orc
     from quadruped_drake_amd import workloads
-    b = workloads.make_batch(3, n=64)
-    rng = np.random.default_rng(0)
-    qperm = rng.permutation(12); aperm = rng.permutation(12)
+    from quadruped_drake_amd.controller import load_model
+    b = workloads.make_batch(cfg, n=256)
+    rng = np.random.default_rng(5)
+    # breadth-first numbering (all abduction joints first) and a random actuator order
+    qperm = np.array([4 * (j % 3) + j // 3 for j in range(12)])
+    aperm = rng.permutation(12)
     q2 = b["q"].copy(); v2 = b["v"].copy()
-    q2[7 + qperm] = b["q"][7:]; v2[6 + qperm] = b["v"][6:]
-    tau, _, _, _ = gpu_step("mptc", b["model"], b["q"], b["v"], b["targets"], b["mask"], act_perm=list(range(12)))
-    tau2, _, _, _ = gpu_step("mptc", b["model"], q2, v2, b["targets"], b["mask"], q_perm=qperm, act_perm=aperm)
-    assert np.array_equal(tau2, tau[aperm])
+    q2[7 + qperm] = b["q"][7:]; v2[6 + qperm] = b["v"][6:]        # canonical joint j lives in row 7 + q_perm[j]
+    tau, met, st, _ = gpu_step(kind, b["model"], q2, v2, b["targets"], b["mask"], q_perm=qperm, act_perm=aperm)
+    table = dict(load_model(b["model"])); table["act_perm"] = [int(x) for x in aperm]
+    tau_o, met_o, st_o = orc.step_batch(kind, orc.model(table), orc.params(kind), b["q"], b["v"], b["targets"], b["mask"])
+    assert (st == 0).all() and (st_o == 0).all()
+    assert rel_err(tau, tau_o).max() < TOL
+    assert np.allclose(met, met_o, rtol=1e-5, atol=1e-6)
+    # and the identity-permutation launch, re-ordered, is the same thing bit for bit
+    tau_id, _, _, _ = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], act_perm=list(range(12)))
+    assert np.array_equal(tau, tau_id[aperm])
 
 
 def test_single_robot_control_law_mirrors_reference_signature():
@@ -221,24 +226,13 @@ def test_full_size_properties(cfg, n):
     ctrl.close()
 
 
-@pytest.mark.parametrize("kind,cfg", [("mptc", 3), ("id", 2), ("pc", 3)])
-def test_three_kernel_mappings_agree_at_full_size(kind, cfg):
-    """The lane-, quad- and 16-lane-per-robot kernels are three independent parallelisations of the same tick
-    (different QR distribution, different active-set bookkeeping): at N = 4096 they agree to solver tolerance
-    and the friction rows hold."""
+def test_pc_passivity_row_holds_at_full_size():
+    """Vdot <= 0 is a hard row of the PC law; it holds to the active set's feasibility tolerance
+    1e-13 (1 + |z|_inf) in normalised units, i.e. times |dVdot/dz| ~ 1e2..1e4 in Vdot units."""
     from quadruped_drake_amd import workloads
-    b = workloads.make_batch(cfg, n=4096)
-    out = {v: gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"], variant=v)
-           for v in ("hex", "quad", "lane")}
-    for v in out:
-        assert (out[v][2] == 0).all()
-    assert rel_err(out["hex"][0], out["lane"][0]).max() < TOL
-    assert rel_err(out["quad"][0], out["lane"][0]).max() < TOL
-    assert np.allclose(out["hex"][1], out["lane"][1], rtol=1e-5, atol=1e-6)
-    if kind == "pc":
-        # Vdot <= 0 is a hard row of the PC law; it holds to the active set's feasibility tolerance
-        # 1e-13 (1 + |z|_inf) in normalised units, i.e. times |dVdot/dz| ~ 1e2..1e4 in Vdot units
-        assert (out["hex"][1][3] <= 1e-7).all() and (out["quad"][1][3] <= 1e-7).all()
+    b = workloads.make_batch(3, n=4096)
+    tau, met, st, _ = gpu_step("pc", b["model"], b["q"], b["v"], b["targets"], b["mask"])
+    assert (st == 0).all() and (met[3] <= 1e-7).all()
 
 
 @pytest.mark.parametrize("cfg,kind,n", [(5, "mptc", 32768), (3, "mptc", 4096), (2, "id", 4096), (4, "mptc", 4096), (3, "pc", 4096), (3, "clf", 4096)])

@@ -71,31 +71,6 @@ def test_permutations():
     assert np.array_equal(tau2, tau[aperm])
 
 
-@pytest.mark.parametrize("cfg,kind,n", [(2, "id", 24), (3, "mptc", 12), (4, "mptc", 8), (5, "mptc", 8), (3, "pc", 24)])
-def test_quad_kernel_math_emulated_on_host(cfg, kind, n):
-    """wbc_quad.hpp (4 lanes = 4 legs per robot) with the quad emulated by 4 host threads."""
-    b = workloads.make_batch(cfg, n=n)
-    t = orc.load_model_json(b["model"])
-    m = orc.model(b["model"]); p = orc.params(kind)
-    tau_o, met_o, st_o = orc.step_batch(kind, m, p, b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
-    tau, met, st, it = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"], quad=True)
-    assert (st == 0).all()
-    assert rel_err(tau, tau_o).max() < 1e-5
-    assert np.allclose(met, met_o, rtol=1e-7, atol=1e-8)
-
-
-def test_quad_all_contact_masks_on_host():
-    b = workloads.make_batch(3, n=16)
-    t = orc.load_model_json("mini_cheetah"); m = orc.model("mini_cheetah")
-    mk = np.arange(16, dtype=np.uint8)
-    for kind in ("id", "mptc"):
-        tau_o, met_o, st_o = orc.step_batch(kind, m, orc.params(kind), b["q"], b["v"], b["targets"], mk)
-        tau, met, st, it = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], mk, quad=True)
-        assert (st == 0).all()
-        assert rel_err(tau, tau_o).max() < 1e-5
-        assert np.allclose(met, met_o, rtol=1e-7, atol=1e-8)
-
-
 @pytest.mark.parametrize("cfg,kind,n", [(2, "id", 24), (3, "mptc", 24), (4, "mptc", 8), (5, "mptc", 8), (3, "pc", 24), (3, "id", 12),
                                         (3, "clf", 24), (2, "clf", 16), (5, "clf", 8)])
 def test_hex_kernel_math_emulated_on_host(cfg, kind, n):
@@ -107,7 +82,7 @@ def test_hex_kernel_math_emulated_on_host(cfg, kind, n):
     tau, met, st, it, vd = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"],
                                   hexv=True, want_vdot=True)
     tq, mq, sq, iq, vdq = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"],
-                                 quad=(kind != "clf"), want_vdot=True)   # CLF: the lane-per-robot mapping (13 variables)
+                                 want_vdot=True)   # the scalar (one-lane-per-robot) instantiation of the same math
     assert (st == 0).all()
     assert rel_err(tau, tau_o).max() < 1e-5
     assert np.allclose(met, met_o, rtol=1e-6, atol=1e-7)
@@ -151,15 +126,15 @@ def test_hex_torque_box(cfg, kind, tmax, mu):
 
 def test_straight_knee_is_reported_not_solved():
     """Known limit of the reduced (task-coordinate) formulation: it inverts every leg's 3x3 foot Jacobian, so a
-    fully straight knee (kinematic singularity) is reported as status 2 with zero torques by all three kernel
-    mappings -- the dense oracle (like the reference's full QP) still solves it.  DESIGN.md section 3."""
+    fully straight knee (kinematic singularity) is reported as status 2 with zero torques by the scalar and the
+    16-lane instantiation -- the dense oracle (like the reference's full QP) still solves it.  DESIGN.md section 3."""
     b = workloads.make_batch(3, n=8)
     t = orc.load_model_json("mini_cheetah")
     q = b["q"].copy()
     q[7 + 2, 0] = 0.0          # LF knee straight
     q[7 + 3 * 2 + 2, 1] = 0.0  # LH knee straight
     for kind in ("mptc", "id"):
-        for kw in ({}, {"quad": True}, {"hexv": True}):
+        for kw in ({}, {"hexv": True}):
             tau, met, st, it = ht.run(kind, t["flat"], q, b["v"], b["targets"], b["mask"], **kw)
             assert st.tolist() == [2, 2, 0, 0, 0, 0, 0, 0]
             assert (tau[:, :2] == 0).all() and np.isfinite(tau).all()

@@ -13,8 +13,8 @@ def test_vdot_of_kernel_math_equals_oracle_qp_vd(cfg, kind):
     """vd is solver-independent (unique): the kernels' reduced solution must reproduce x[:18] of the literal QP."""
     b = workloads.make_batch(cfg, n=24)
     t = orc.load_model_json(b["model"]); m = orc.model(b["model"]); p = orc.params(kind)
-    for quad in ((False, True) if kind != "clf" else (False,)):
-        _, _, st, _, vd = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], quad=quad, want_vdot=True)
+    for hexv in (False, True):
+        _, _, st, _, vd = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], hexv=hexv, want_vdot=True)
         for i in range(24):
             ct = [(int(b["mask"][i]) >> k) & 1 for k in range(4)]
             _, _, _, qp = orc.control_law(kind, m, p, b["q"][:, i], b["v"][:, i], b["targets"][:, i], ct, want_qp=True)
@@ -55,6 +55,66 @@ def test_gpu_vdot_and_integrate_match_oracles():
     q_o, v_o = to.integrate(b["q"], b["v"], vd.cpu().numpy(), 5e-3)
     assert np.allclose(q.cpu().numpy(), q_o, rtol=0, atol=1e-14) and np.allclose(v.cpu().numpy(), v_o, rtol=0, atol=1e-14)
     ctrl.set_vdot_output(None)
+    ctrl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,kind", [(3, "mptc"), (2, "id"), (3, "pc"), (3, "clf"), (5, "mptc")])
+def test_gpu_vdot_equals_oracle_qp_vd(cfg, kind):
+    """The device's generalized accelerations against x[:18] of the ORACLE's literal 30+3nc-variable QP (the
+    solver-independent, unique part of the solution), for every law."""
+    import torch
+    from quadruped_drake_amd import IDController, MPTCController, PCController, CLFController
+    n = 96
+    b = workloads.make_batch(cfg, n=n)
+    cls = {"id": IDController, "mptc": MPTCController, "pc": PCController, "clf": CLFController}[kind]
+    ctrl = cls(model=b["model"], max_batch=n, device=0)
+    up = lambda x: None if x is None else torch.tensor(x, device="cuda:0")
+    vd = torch.full((18, n), float("nan"), dtype=torch.float64, device="cuda:0")
+    ctrl.set_vdot_output(vd)
+    tau, met, st = ctrl.step(up(b["q"]), up(b["v"]), up(b["targets"]), up(b["mask"]), up(b["mu"]), up(b["mass_scale"]))
+    ctrl.sync()
+    ctrl.set_vdot_output(None)
+    ctrl.close()
+    vd = vd.cpu().numpy()
+    assert (st.cpu().numpy() == 0).all() and np.isfinite(vd).all()
+    m = orc.model(b["model"])
+    for i in range(n):
+        p = orc.params(kind)
+        if b["mu"] is not None:
+            p.mu = float(b["mu"][i])
+        mi = m if b["mass_scale"] is None else orc.model_scaled(b["model"], float(b["mass_scale"][i]))
+        ct = [(int(b["mask"][i]) >> k) & 1 for k in range(4)]
+        _, _, st_o, qp = orc.control_law(kind, mi, p, b["q"][:, i], b["v"][:, i], b["targets"][:, i], ct, want_qp=True)
+        assert st_o == 0
+        assert np.abs(vd[:, i] - qp["x"][:18]).max() < 1e-8 * (1 + np.abs(qp["x"][:18]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["id", "mptc"])
+def test_rollout_with_a_singular_instance_stays_finite(kind):
+    """A straight knee (|det J_l| < 1e-12) is reported (status 2) with zero torques AND zero accelerations, so the
+    closed loop integrates defined values: q, v stay finite, the caller's (uninitialised) vdot buffer is never read."""
+    import torch
+    from quadruped_drake_amd import IDController, MPTCController
+    from quadruped_drake_amd.trajectory import TrunkTrajectory
+    n = 8
+    q0, v0 = workloads.nominal_state("mini_cheetah", n)
+    q0[7 + 2, 0] = 0.0; q0[7 + 1, 0] = 0.0          # robot 0: LF knee and hip straight -> singular leg Jacobian
+    st_t = workloads.standing_targets("mini_cheetah", 1)[:, 0]
+    traj = TrunkTrajectory(np.zeros(0), np.zeros((0, 54)), np.zeros(0, np.uint8), wait_time=1e9, device=0,
+                           standing_targets=st_t, standing_mask=0b1111)
+    cls = IDController if kind == "id" else MPTCController
+    ctrl = cls(max_batch=n, device=0)
+    q = torch.tensor(q0, device="cuda:0"); v = torch.tensor(v0, device="cuda:0")
+    time = torch.zeros(n, dtype=torch.float64, device="cuda:0")
+    tau, met, st, tg, mk = ctrl.rollout(traj, 5, 1e-3, q, v, time)
+    ctrl.sync()
+    st = st.cpu().numpy(); qf = q.cpu().numpy(); vf = v.cpu().numpy()
+    assert st[0] == 2 and (st[1:] == 0).all()
+    assert np.isfinite(qf).all() and np.isfinite(vf).all() and np.isfinite(tau.cpu().numpy()).all()
+    assert np.array_equal(qf[:, 0], q0[:, 0]) and np.array_equal(vf[:, 0], v0[:, 0])    # zero accelerations from rest: frozen
+    assert (tau.cpu().numpy()[:, 0] == 0).all()
     ctrl.close()
 
 

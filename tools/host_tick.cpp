@@ -114,102 +114,7 @@ int host_tick_count(int kind, const double* flat215, const double* params12, int
 }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Host emulation of the quad-per-robot kernel (wbc_quad.hpp): 4 threads play the 4 lanes of a
-// quad; every cross-lane DPP op becomes "publish to a slot, barrier, read, barrier".
-#include <barrier>
-#include <thread>
 #include <vector>
-#include "../quadruped_drake_amd/csrc/wbc_quad.hpp"
-
-struct QuadCtx {
-  std::barrier<> bar{4};
-  double slot[4];
-  int islot[4];
-};
-struct QuadHost {
-  int l;
-  QuadCtx* c;
-  int lane() const { return l; }
-  double bcast_s(double x, int src) {
-    c->slot[l] = x; c->bar.arrive_and_wait();
-    double r = c->slot[src]; c->bar.arrive_and_wait();
-    return r;
-  }
-  double bcast_d(double x, int src) { return bcast_s(x, src); }
-  double sum(double x) {  // same association as the DPP butterfly: (x_l + x_{l^1}) + (x_{l^2} + x_{l^3})
-    c->slot[l] = x; c->bar.arrive_and_wait();
-    double a = c->slot[l] + c->slot[l ^ 1], b = c->slot[l ^ 2] + c->slot[l ^ 3];
-    c->bar.arrive_and_wait();
-    return a + b;
-  }
-  double max(double x) {
-    c->slot[l] = x; c->bar.arrive_and_wait();
-    double r = fmax(fmax(c->slot[0], c->slot[1]), fmax(c->slot[2], c->slot[3]));
-    c->bar.arrive_and_wait();
-    return r;
-  }
-  bool wave_all(bool b) { return b; }
-  int wave_max_int(int x) { return x; }  // one quad per "wave" in the emulation; b is replicated
-  bool any(bool b) {
-    c->islot[l] = b; c->bar.arrive_and_wait();
-    bool r = c->islot[0] | c->islot[1] | c->islot[2] | c->islot[3];
-    c->bar.arrive_and_wait();
-    return r;
-  }
-  void argmin(double& v, int& i) {
-    c->slot[l] = v; c->islot[l] = i; c->bar.arrive_and_wait();
-    double bv = c->slot[0]; int bi = c->islot[0];
-    for (int k = 1; k < 4; k++) {
-      double ov = c->slot[k]; int oi = c->islot[k];
-      if (ov < bv || (ov == bv && oi >= 0 && (bi < 0 || oi < bi))) { bv = ov; bi = oi; }
-    }
-    c->bar.arrive_and_wait();
-    v = bv; i = bi;
-  }
-};
-
-extern "C" int host_quad_batch(int kind, const double* flat215, const double* params12, const int* q_perm,
-                               const int* act_perm, int n, int stride, const double* q, const double* v,
-                               const double* tg, const unsigned char* mask, const double* mu,
-                               const double* mass_scale, double* tau, double* met, int* status, int* iters) {
-  wbc::ModelC m;
-  if (wbc::model_from_flat(flat215, &m)) return -1;
-  wbc::model_set_perms(&m, q_perm, act_perm);
-  wbc::ParamsC P;
-  wbc::params_default(kind, &P);
-  if (params12) memcpy(&P, params12, sizeof(double) * 12);
-  QuadCtx ctx;
-  auto worker = [&](int l) {
-    QuadHost qo{l, &ctx};
-    wbc::QuadShared sh;  // replicated per lane on the host (shared LDS with replicated writes on the device)
-    memset(&sh, 0, sizeof sh);
-    for (int i = 0; i < n; i++) {
-      auto in = [&](int r) -> double {
-        if (r < 19) return q[(size_t)r * stride + i];
-        if (r < 37) return v[(size_t)(r - 19) * stride + i];
-        return tg[(size_t)(r - 37) * stride + i];
-      };
-      auto ot = [&](int k, double x) { tau[(size_t)k * stride + i] = x; };
-      auto om = [&](int k, double x) {
-        if (k >= 4) { if (g_vdot && (k >= 10 || l == 0)) g_vdot[(size_t)(k - 4) * stride + i] = x; return; }
-        if (l == 0 && met) met[(size_t)k * stride + i] = x;
-      };
-      int it = 0, st;
-      double mui = mu ? mu[i] : P.mu, msi = mass_scale ? mass_scale[i] : 1.0;
-      wbc::LegKin<double> K;
-      wbc::StageReg<double> sg;
-      if (kind == wbc::KIND_ID) st = wbc::quad_tick<QuadHost, wbc::KIND_ID>(m, P, qo, in, mask[i], mui, msi, K, sg, sh, ot, om, &it);
-      else if (kind == wbc::KIND_PC) st = wbc::quad_tick<QuadHost, wbc::KIND_PC>(m, P, qo, in, mask[i], mui, msi, K, sg, sh, ot, om, &it);
-      else st = wbc::quad_tick<QuadHost, wbc::KIND_MPTC>(m, P, qo, in, mask[i], mui, msi, K, sg, sh, ot, om, &it);
-      if (l == 0) { if (status) status[i] = st; if (iters) iters[i] = it; }
-    }
-  };
-  std::vector<std::thread> th;
-  for (int l = 0; l < 4; l++) th.emplace_back(worker, l);
-  for (auto& t : th) t.join();
-  return 0;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Host emulation of the 16-lanes-per-robot kernel (wbc_hex.hpp): 16 cooperative fibres (ucontext,

@@ -41,6 +41,9 @@ for gi, grp in enumerate(a.groups):
     launches = {}
     for (kn, cn), (s, c) in acc.items():
         launches[kn] = max(launches.get(kn, 0), c)
+    if not launches:                               # a pass that produced no wbc_* rows (profiler refused the counters, ...)
+        res.setdefault("empty_passes", []).append(grp)
+        continue
     hot = max(launches, key=launches.get)          # the hot kernel = the wbc_* kernel with the most launches
     for (kn, cn), (s, c) in acc.items():
         if kn == hot:
