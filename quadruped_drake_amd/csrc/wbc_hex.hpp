@@ -19,6 +19,8 @@
 // `Q` is the communication policy: HexDev (wbc_kernels.hip) on the GPU, a 16-fibre lock-step
 // emulation in tools/host_tick.cpp for CPU-side validation.
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "wbc_tick.hpp"
 // WBC_QRF bit 0: hardware-seeded sqrt in the Householder steps; bit 1: the same for the reciprocal (measured:
 // bit 1 makes the MPTC kernel spill, bit 0 saves ~240 instructions; profiles/r01/hex_cuts.md)
@@ -27,6 +29,11 @@
 #endif
 
 namespace wbc {
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(integral_constant<int, N-1>{}) -- the index is a
+// constant expression inside the body (the fused broadcast-FMA takes its source lane as an immediate)
+template <class F, int... I> WBC_HD void static_for_impl(F& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> WBC_HD void static_for(F f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // lane (within the 16-lane row) that owns z-space column / row k = 3*leg + coordinate; the CLF law's 13th
 // reduced variable (the slack delta, k = 12) lives on the spare sub-lane 3 of leg 1
@@ -37,18 +44,33 @@ WBC_HD constexpr int hex_lane(int k) { return k < 12 ? 4 * (k / 3) + (k % 3) : H
 // Lane hex_lane(c) holds column c: Rcol[12], Acol[P]; the lanes with sub == 3 hold the right-hand side
 // as one more column.  Already-pivoted columns are left with O(ulp) residue below the diagonal of R
 // (never read) instead of being zeroed: no per-step predication.
+// A pivot step costs 2 P + ~45 instructions: the pivot column is never copied -- both the dot product and the
+// update read it straight from the pivot lane with the fused broadcast-FMA (Q::fma_bc = v_fmac_f64_dpp).
 template <class Q, int P, int NV = NZ>
 WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
-#pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const int piv = hex_lane(k);
-    double col[P];
-    double t = 0.0;
-#pragma unroll
-    for (int i = 0; i < P; i++) {
-      col[i] = qo.bcast16(Acol[i], piv);
-      t += col[i] * Acol[i];
+  qo.template dpp_fence<P>(Acol);
+  static_for<NV>([&](auto K) {
+    constexpr int k = K;
+    constexpr int piv = hex_lane(k);
+    // three accumulators, the terms in blocks of <= 15 fused ops (one asm statement each: Q::dot_bc)
+    double ta = 0.0, tb = 0.0, tc = 0.0;
+    {
+      constexpr int C0 = (P >= 15) ? 15 : (P >= 9 ? 9 : (P >= 6 ? 6 : 3));
+      static_assert(P % 3 == 0, "row count is a multiple of three");
+      qo.template dot_bc<piv, C0>(ta, tb, tc, Acol);
+      constexpr int R1 = P - C0;
+      if constexpr (R1 > 0) {
+        constexpr int C1 = (R1 >= 15) ? 15 : (R1 >= 9 ? 9 : (R1 >= 6 ? 6 : 3));
+        qo.template dot_bc<piv, C1>(ta, tb, tc, Acol + C0);
+        constexpr int R2 = R1 - C1;
+        if constexpr (R2 > 0) {
+          constexpr int C2 = (R2 >= 15) ? 15 : (R2 >= 9 ? 9 : (R2 >= 6 ? 6 : 3));
+          qo.template dot_bc<piv, C2>(ta, tb, tc, Acol + C0 + C1);
+          static_assert(R2 - C2 == 0, "at most three blocks");
+        }
+      }
     }
+    const double t = (ta + tb) + tc;
     const double s2 = qo.bcast16(t, piv);
     const double rkk = qo.bcast16(Rcol[k], piv);
 #if WBC_QRF & 1
@@ -63,11 +85,10 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
 #else
     const double beta = (s2 > 0.0) ? 1.0 / (nrm * (nrm + fabs(rkk))) : 0.0;
 #endif  // = 2 / (s2 + v0^2); empty column: no-op
-    const double s = (v0 * Rcol[k] + t) * beta;
-    Rcol[k] -= s * v0;
-#pragma unroll
-    for (int i = 0; i < P; i++) Acol[i] -= s * col[i];
-  }
+    const double ns = -((v0 * Rcol[k] + t) * beta);
+    Rcol[k] += ns * v0;
+    static_for<P>([&](auto I) { Acol[I] = qo.template fma_bc<piv>(Acol[I], Acol[I], ns); });
+  });
 }
 
 // 16-lane argmin as ONE fmin butterfly: the 5-bit candidate index rides in the low mantissa bits of the value
@@ -800,22 +821,30 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   // level-2 rows eps (T z + t0):  T[(l',i)][(l,j)] = Y_l'[i] . B_l[:,j] + delta D_l[i][j].  (Folding them into
   // the level-1 append -- one pass of 12 pivots over 30 rows -- was measured: it spills, profiles/r02.)
   auto level2_rows = [&](double* A2) {
-#pragma unroll
-    for (int r = 0; r < NZ; r++) {
-      const int src = hex_lane(r);
-      double dotv = 0.0;
-#pragma unroll
-      for (int k = 0; k < 6; k++) dotv += qo.bcast16(Yrow[k], src) * bcol[k];
-      const double t0r = qo.bcast16(t0_own, src);
-      const double dg = (r / 3 == l) ? Dcol[r % 3] : 0.0;
-      A2[r] = colv ? eps * (dotv + dg) : (cold ? 0.0 : -eps * (t0r + dotv));
-    }
+    qo.template dpp_fence<6>(Yrow);
+    static_for<NZ / 3>([&](auto RR) {
+      // three rows at a time, their fused chains interleaved (an inline-asm result is not read for two instructions)
+      constexpr int r0 = 3 * RR, r1 = r0 + 1, r2 = r0 + 2;
+      constexpr int s0 = hex_lane(r0), s1 = hex_lane(r1), s2 = hex_lane(r2);
+      // column lanes: D_l entry + Y_row . B_col ;  rhs lanes: t0_row + Y_row . ab0   (one fused broadcast-FMA per term)
+      const double t0a = qo.bcast16(t0_own, s0), t0b = qo.bcast16(t0_own, s1), t0c = qo.bcast16(t0_own, s2);
+      const bool own = (r0 / 3 == l);   // rows r0..r2 belong to leg RR
+      double da = colv ? (own ? Dcol[0] : 0.0) : t0a;
+      double db = colv ? (own ? Dcol[1] : 0.0) : t0b;
+      double dc = colv ? (own ? Dcol[2] : 0.0) : t0c;
+      qo.template rows3_bc<s0, s1, s2>(da, db, dc, Yrow, bcol);
+      A2[r0] = colv ? eps * da : (cold ? 0.0 : -eps * da);
+      A2[r1] = colv ? eps * db : (cold ? 0.0 : -eps * db);
+      A2[r2] = colv ? eps * dc : (cold ? 0.0 : -eps * dc);
+    });
   };
+  // Level-1 rows (P1 of them) and the 12 level-2 rows are folded in ONE append of P1 + 12 rows: 12 pivot steps
+  // instead of 24 (the fused broadcast-FMA needs no copy of the pivot column, so 30 rows fit the registers).
+  constexpr int P1 = (KIND == KIND_ID || KIND == KIND_CLF) ? 6 : 18;
+  double Acol[P1 + NZ];
   if (KIND == KIND_ID) {
-    double Acol[6];
     for (int i = 0; i < 6; i++) Acol[i] = colv ? sw_b * bcol[i] : sw_b * (ades[i] - bcol[i]);
     init_rcol();
-    hex_qr_append<Q, 6>(qo, Rcol, Acol);
   } else if (KIND == KIND_CLF) {
     // ---------------- CLF-QP in task coordinates, unit weights on every task row (see wbc_tick.hpp for the
     // lane-per-robot original; gains are the literals of clf_controller.py:65-73)
@@ -823,7 +852,6 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     const double pb12 = sqrt(Qp_b * rr), pb22 = sqrt(rr * (Qd_b + 2.0 * pb12)), pb11 = pb12 * pb22 / rr;   // CARE, closed form (:187)
     const double pf12 = sqrt(Qp_f * rr), pf22 = sqrt(rr * (Qd_f + 2.0 * pf12)), pf11 = pf12 * pf22 / rr;
     double V = 0.0, ePFe = 0.0, ub = 0.0, gdot = 0.0, gxdd = 0.0;
-    double Acol[6];
     for (int i = 0; i < 6; i++) {
       const double pg = pb12 * xt_b[i] + pb22 * xdt_b[i], gt = 2.0 * pg;
       V += pb11 * xt_b[i] * xt_b[i] + 2.0 * pb12 * xt_b[i] * xdt_b[i] + pb22 * xdt_b[i] * xdt_b[i];
@@ -856,7 +884,6 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     clf_c0 = 2.0 * ePFe - gxdd + gs_jx;
     met_V = V;
     init_rcol();
-    hex_qr_append<Q, 6, NV>(qo, Rcol, Acol);
   } else {
     // ---- MPTC in task coordinates (derivation: wbc_tick.hpp / DESIGN.md)
     double MiY[18], Mt_bl[18], Mt_ll[9];
@@ -919,7 +946,6 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       met_V += qo.legs_sum(lv);
       met_Vdot += qo.legs_sum(lvd);
     }
-    double Acol[18];
     {
       // (Ji Jfb)' Y = [ rf x M ; M ] with M = Ji' Y (= Mt_bl, already formed): column j of the top block is rf x M[:, j]
       // column lanes: vrow_own = [swing] Lx_s[sub] + sum_i lx_i B[i][col];  rhs lanes: the same dot gives vconst
@@ -961,26 +987,27 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       for (int k = 0; k < 6; k++) Msb[k] = ct ? 0.0 : pick3(sb, Mt_bl[3 * k], Mt_bl[3 * k + 1], Mt_bl[3 * k + 2]);
       for (int i = 0; i < 3; i++) Msc[i] = ct ? 0.0 : pick3(sb, Mt_ll[3 * i], Mt_ll[3 * i + 1], Mt_ll[3 * i + 2]);
       const double c1o = ct ? 0.0 : pick3(sb, c1_s[0], c1_s[1], c1_s[2]);
-#pragma unroll
-      for (int r = 0; r < NZ; r++) {
-        const int src = hex_lane(r);
-        double dotv = 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) dotv += qo.bcast16(Msb[k], src) * bcol[k];
-        const double c1r = qo.bcast16(c1o, src);
-        const double dg = (r / 3 == l) ? Msc[r % 3] : 0.0;   // Lambda_ss entry (row r, own column): own leg only
-        Acol[6 + r] = colv ? sw_f * (dotv + dg) : -sw_f * (c1r + dotv);
-      }
+      qo.template dpp_fence<6>(Msb);
+      static_for<NZ / 3>([&](auto RR) {
+        constexpr int r0 = 3 * RR, r1 = r0 + 1, r2 = r0 + 2;
+        constexpr int s0 = hex_lane(r0), s1 = hex_lane(r1), s2 = hex_lane(r2);
+        // column lanes: Lambda_ss entry (row r, own column; own leg only) + Lambda_sb row . B_col ;  rhs lanes: c1_row + Lambda_sb row . ab0
+        const double c1a = qo.bcast16(c1o, s0), c1b = qo.bcast16(c1o, s1), c1c = qo.bcast16(c1o, s2);
+        const bool own = (r0 / 3 == l);
+        double da = colv ? (own ? Msc[0] : 0.0) : c1a;
+        double db = colv ? (own ? Msc[1] : 0.0) : c1b;
+        double dc = colv ? (own ? Msc[2] : 0.0) : c1c;
+        qo.template rows3_bc<s0, s1, s2>(da, db, dc, Msb, bcol);
+        Acol[6 + r0] = colv ? sw_f * da : -sw_f * da;
+        Acol[6 + r1] = colv ? sw_f * db : -sw_f * db;
+        Acol[6 + r2] = colv ? sw_f * dc : -sw_f * dc;
+      });
     }
     init_rcol();
-    hex_qr_append<Q, 18>(qo, Rcol, Acol);
   }
-  WBC_HCUT_AT(4, Rcol[0] + Rcol[5] + Rcol[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
-  {
-    double A2[NZ];
-    level2_rows(A2);
-    hex_qr_append<Q, NZ, NV>(qo, Rcol, A2);
-  }
+  WBC_HCUT_AT(4, Acol[0] + Acol[5] + Acol[P1 - 1] + Rcol[0] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
+  level2_rows(Acol + P1);
+  hex_qr_append<Q, P1 + NZ, NV>(qo, Rcol, Acol);
   WBC_HCUT_AT(5, Rcol[0] + Rcol[5] + Rcol[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- own row of J = R^-1 and unconstrained minimiser
   double z, Jr[NV];
@@ -1011,14 +1038,20 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     // my row index rr = 3*l + sb (column lanes; 12 on the delta lane).  J[rr][c] = (delta_rr,c - sum_{k<c} J[rr][k] R[k][c]) / R[c][c]
     const int rr = cold ? NZ : 3 * l + sb;
     double zacc = 0.0;
-#pragma unroll
-    for (int c = 0; c < NV; c++) {
-      double s = ((colv || cold) && c == rr) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < c; k++) s -= Jr[k] * qo.bcast16(Rcol[k], hex_lane(c));
-      Jr[c] = s * invd[c];
-      zacc += Jr[c] * qo.bcast16(Rcol[c], 3);   // rhs column after the appends (lane (0,3))
-    }
+    qo.template dpp_fence<NV>(Rcol);
+    static_for<NV>([&](auto CC) {
+      constexpr int c = CC;
+      double s = ((colv || cold) && c == rr) ? -1.0 : 0.0;   // the NEGATIVE of the row entry accumulates (no per-term negation)
+      double sb2 = 0.0, sc2 = 0.0;                            // three accumulators: no fused op reads the result of the two before it
+      static_for<c>([&](auto KK) {
+        if constexpr (KK % 3 == 0) s = qo.template fma_bc<hex_lane(c)>(s, Rcol[KK], Jr[KK]);
+        else if constexpr (KK % 3 == 1) sb2 = qo.template fma_bc<hex_lane(c)>(sb2, Rcol[KK], Jr[KK]);
+        else sc2 = qo.template fma_bc<hex_lane(c)>(sc2, Rcol[KK], Jr[KK]);
+      });
+      if (c > 2) s += sb2 + sc2; else if (c > 1) s += sb2;
+      Jr[c] = -s * invd[c];
+      zacc = qo.template fma_bc<3>(zacc, Rcol[c], Jr[c]);   // rhs column after the appends (lane (0,3))
+    });
     z = zacc;
   }
   WBC_HCUT_AT(6, z + Jr[0] + Jr[5] + Jr[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])

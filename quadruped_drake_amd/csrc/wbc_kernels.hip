@@ -94,6 +94,59 @@ struct HexDev {
       case 12: return dpp<0x15C>(x);  case 13: return dpp<0x15D>(x);  case 14: return dpp<0x15E>(x);  default: return dpp<0x15F>(x);
     }
   }
+  // acc + bcast16(x, src) * y as ONE instruction: v_fmac_f64_dpp with row_newbcast (the one DPP control the DP ALU
+  // takes; the compiler never folds v_mov_b64_dpp into its consumer, profiles/r02/dpp_fmac.md).  The compiler's hazard
+  // recogniser does not see a DPP read inside inline asm, so the "VALU write -> DPP read of the same VGPR needs 2 wait
+  // states" rule is kept by construction: the asms are volatile (they stay in program order among themselves) and
+  // every array that is DPP-read this way passes through dpp_fence() first (all its producers before the fence's
+  // s_nop, all DPP reads after); a value these asms PRODUCE is fenced before compiler-generated DPP code reads it.
+  template <int SRC> __device__ __forceinline__ double fma_bc(double acc, double x, double y) const {
+    static_assert(SRC >= 0 && SRC < 16, "row_newbcast lane");
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(SRC));
+    return acc;
+  }
+  // Blocks of fused ops as ONE asm statement.  The hazard recogniser counts an inline-asm statement as zero wait
+  // states and assumes its result may be read by the next one, so a run of single-instruction asms that accumulate
+  // gets an s_nop per round (one per three ops with three accumulators, profiles/r02/dpp_fmac.md); inside one
+  // statement the hardware's own interlocks order the dependent v_fmac_f64 (as in compiler-generated chains).
+#define WBC_FD(A, X) "v_fmac_f64_dpp %" #A ", %" #X ", %" #X " row_newbcast:%[ln] row_mask:0xf bank_mask:0xf\n\t"
+  // (ta, tb, tc) += sum over i of bcast16(a[i], SRC) * a[i], term i on accumulator i % 3
+  template <int SRC, int N> __device__ __forceinline__ void dot_bc(double& ta, double& tb, double& tc, const double* a) const {
+    static_assert(N == 15 || N == 9 || N == 6 || N == 3, "chunk sizes");
+    if constexpr (N == 15)
+      asm volatile(WBC_FD(0, 3) WBC_FD(1, 4) WBC_FD(2, 5) WBC_FD(0, 6) WBC_FD(1, 7) WBC_FD(2, 8) WBC_FD(0, 9) WBC_FD(1, 10) WBC_FD(2, 11) WBC_FD(0, 12) WBC_FD(1, 13) WBC_FD(2, 14) WBC_FD(0, 15) WBC_FD(1, 16) WBC_FD(2, 17)
+                   : "+v"(ta), "+v"(tb), "+v"(tc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), [ln] "n"(SRC));
+    else if constexpr (N == 9)
+      asm volatile(WBC_FD(0, 3) WBC_FD(1, 4) WBC_FD(2, 5) WBC_FD(0, 6) WBC_FD(1, 7) WBC_FD(2, 8) WBC_FD(0, 9) WBC_FD(1, 10) WBC_FD(2, 11)
+                   : "+v"(ta), "+v"(tb), "+v"(tc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), [ln] "n"(SRC));
+    else if constexpr (N == 6)
+      asm volatile(WBC_FD(0, 3) WBC_FD(1, 4) WBC_FD(2, 5) WBC_FD(0, 6) WBC_FD(1, 7) WBC_FD(2, 8)
+                   : "+v"(ta), "+v"(tb), "+v"(tc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), [ln] "n"(SRC));
+    else if constexpr (N == 3)
+      asm volatile(WBC_FD(0, 3) WBC_FD(1, 4) WBC_FD(2, 5)
+                   : "+v"(ta), "+v"(tb), "+v"(tc) : "v"(a[0]), "v"(a[1]), "v"(a[2]), [ln] "n"(SRC));
+  }
+#undef WBC_FD
+#define WBC_FP(A, X, Y, L) "v_fmac_f64_dpp %" #A ", %" #X ", %" #Y " row_newbcast:%[" #L "] row_mask:0xf bank_mask:0xf\n\t"
+  // three rows of an all-pairs block: d_j += sum over k < 6 of bcast16(x[k], Lj) * y[k]
+  template <int L0, int L1, int L2> __device__ __forceinline__ void rows3_bc(double& d0, double& d1, double& d2, const double* x, const double* y) const {
+    asm volatile(WBC_FP(0, 3, 9, l0) WBC_FP(1, 3, 9, l1) WBC_FP(2, 3, 9, l2) WBC_FP(0, 4, 10, l0) WBC_FP(1, 4, 10, l1) WBC_FP(2, 4, 10, l2) WBC_FP(0, 5, 11, l0) WBC_FP(1, 5, 11, l1) WBC_FP(2, 5, 11, l2) WBC_FP(0, 6, 12, l0) WBC_FP(1, 6, 12, l1) WBC_FP(2, 6, 12, l2) WBC_FP(0, 7, 13, l0) WBC_FP(1, 7, 13, l1) WBC_FP(2, 7, 13, l2) WBC_FP(0, 8, 14, l0) WBC_FP(1, 8, 14, l1) WBC_FP(2, 8, 14, l2)
+                 : "+v"(d0), "+v"(d1), "+v"(d2)
+                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]),
+                   [l0] "n"(L0), [l1] "n"(L1), [l2] "n"(L2));
+  }
+#undef WBC_FP
+  // s_nop 4 = 5 wait states: covers the DPP-source rule (2) and "VALU wrote EXEC" (5)
+  template <int N> static __device__ __forceinline__ void dpp_fence(double* a) {
+    if constexpr (N >= 6) {
+      asm volatile("s_nop 4" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]));
+      dpp_fence<N - 6>(a + 6);
+    } else if constexpr (N == 5) { asm volatile("s_nop 4" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4])); }
+    else if constexpr (N == 4) { asm volatile("s_nop 4" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])); }
+    else if constexpr (N == 3) { asm volatile("s_nop 4" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2])); }
+    else if constexpr (N == 2) { asm volatile("s_nop 4" : "+v"(a[0]), "+v"(a[1])); }
+    else if constexpr (N == 1) { asm volatile("s_nop 1" : "+v"(a[0])); }
+  }
   __device__ __forceinline__ double leg_bcast(double x, int s0) const {
     switch (s0) {
       case 0: return dpp<0x00>(x);

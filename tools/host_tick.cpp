@@ -174,6 +174,17 @@ struct HexHost {
     return r;
   }
   double bcast16(double x, int src) { return xchg(x, src); }
+  template <int SRC> double fma_bc(double acc, double x, double y) { return acc + xchg(x, SRC) * y; }   // device: one v_fmac_f64_dpp
+  template <int N> static void dpp_fence(double*) {}                                            // device: hazard fence
+  template <int SRC, int N> void dot_bc(double& ta, double& tb, double& tc, const double* a) {
+    for (int i = 0; i < N; i++) {
+      const double t = xchg(a[i], SRC) * a[i];
+      if (i % 3 == 0) ta += t; else if (i % 3 == 1) tb += t; else tc += t;
+    }
+  }
+  template <int L0, int L1, int L2> void rows3_bc(double& d0, double& d1, double& d2, const double* x, const double* y) {
+    for (int k = 0; k < 6; k++) { d0 += xchg(x[k], L0) * y[k]; d1 += xchg(x[k], L1) * y[k]; d2 += xchg(x[k], L2) * y[k]; }
+  }
   double leg_bcast(double x, int s0) { return xchg(x, (h & ~3) | s0); }
   double leg_pairs(double x) { return xchg(x, (h & ~3) | ((h & 3) >> 1)); }   // quad_perm [0,0,1,1]
   double bcast16d(double x, int src) { return xchg(x, src); }                  // dynamic (robot-uniform) source lane
