@@ -22,10 +22,26 @@
 #include <type_traits>
 #include <utility>
 #include "wbc_tick.hpp"
-// WBC_QRF bit 0: hardware-seeded sqrt in the Householder steps; bit 1: the same for the reciprocal (measured:
-// bit 1 makes the MPTC kernel spill, bit 0 saves ~240 instructions; profiles/r01/hex_cuts.md)
+// WBC_QRF bit 0: hardware-seeded sqrt in the Householder steps; bit 1: the same for the reciprocal (round 1: bit 1
+// made the MPTC kernel spill; with the single 30-row append of round 2 it does not and saves ~140 instructions)
 #ifndef WBC_QRF
-#define WBC_QRF 1
+#define WBC_QRF 3
+#endif
+
+// host-only diagnostics (tools/host_tick.cpp): how many fast / generic active-set trips a robot ran
+#if !defined(__HIPCC__) && defined(WBC_HOST_GI_STATS)
+extern int g_gi_fast_trips, g_gi_generic_trips, g_gi_drops, g_gi_force_bail;
+#define WBC_GI_FORCE_BAIL(qc) (g_gi_force_bail == (qc))
+#define WBC_GI_STAT(x) do { x; } while (0)
+#else
+#define WBC_GI_STAT(x) do { } while (0)
+#endif
+#ifndef WBC_GI_FORCE_BAIL
+#ifdef WBC_DEV_FORCE_BAIL   // diagnostic device builds: every wavefront leaves the fast path at trip WBC_DEV_FORCE_BAIL
+#define WBC_GI_FORCE_BAIL(qc) ((qc) == WBC_DEV_FORCE_BAIL)
+#else
+#define WBC_GI_FORCE_BAIL(qc) false
+#endif
 #endif
 
 namespace wbc {
@@ -90,6 +106,10 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
     static_for<P>([&](auto I) { Acol[I] = qo.template fma_bc<piv>(Acol[I], Acol[I], ns); });
   });
 }
+
+// Explicit fused multiply-add: the active set's fast and generic paths must round identically (a robot's result may
+// not depend on which path its wavefront took), so nothing there is left to the compiler's contraction choices.
+WBC_HD double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
 // 16-lane argmin as ONE fmin butterfly: the 5-bit candidate index rides in the low mantissa bits of the value
 // (a 2^-47 relative perturbation of the returned minimum; "no candidate" is the finite HEX_NONE, never inf, so
@@ -188,7 +208,92 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   const double INF = __builtin_huge_val();
   // feasibility tolerance from the scale of the unconstrained minimiser (the iterates stay on that scale)
   const double tol = 1e-13 * (1.0 + qo.max16(fabs(z)));
-  for (int trip = 0; trip < maxit; trip++) {
+  // ---- Fast path (plain friction rows only): the first trips of a tick are almost always "add the picked row with a
+  // full step" on every robot of the wavefront, so the list length q is wave-uniform and equals the trip number.  With q
+  // a compile-time constant the position masks, their shifts and all work on the fixed positions k < q disappear
+  // (~230 instead of ~570 instructions per trip, profiles/r02/hex_cuts.md).  The moment any robot of the wavefront
+  // needs something else (a partial step = a drop, a dependent row) the trip is abandoned BEFORE it has changed any
+  // state and the generic loop below takes over.  Both paths evaluate the same expressions in the same order, so a
+  // robot's result does not depend on which path its wavefront took (bit-identical; tests: batch-position invariance).
+  constexpr int QF = (!PC && !TB && NV == NZ) ? 8 : 0;
+  bool generic = true;   // wave-uniform: the generic loop still has work to do
+  if constexpr (QF > 0) {
+    bool stop = false;   // wave-uniform
+    static_for<QF>([&](auto QQ) {
+      constexpr int qc = QQ;
+      if (stop) return;
+      // pick (a finished robot offers no candidate)
+      int pf;
+      {
+        double key = HEX_NONE;
+        if (!done && ct && !((active >> h) & 1ull)) {
+          if (GAIN) {
+            double dd2 = 0.0;
+            static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; dd2 = fmad(Dh[k], Dh[k], dd2); });
+            if (sh_ < -tol) key = hex_pack_key((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
+          } else {
+            key = hex_pack_key(sh_, h);
+          }
+        }
+        key = qo.min16(key);
+        pf = (key < 1e299) ? hex_key_index(key) : -1;
+      }
+      // ONE round trip: the picked row's image, value and norm from its lane (own lane when there is no candidate)
+      const int pl = (pf >= 0) ? pf : h;
+      double d[NZ];
+#pragma unroll
+      for (int k = 0; k < NZ; k++) d[k] = qo.bcast16d(Dh[k], pl);
+      const double spx = qo.bcast16d(sh_, pl), dnx = qo.bcast16d(dnh, pl);
+      if (!(pf >= 0 && spx < -tol)) done = true;        // nothing (left) to repair on this robot
+      if (qo.wave_all(done)) { stop = true; generic = false; return; }
+      double d2n = 0.0, zd = 0.0, sd = 0.0, r_h = 0.0;
+      static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; d2n = fmad(d[k], d[k], d2n); });
+      static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; zd = fmad(Jr[k], d[k], zd); sd = fmad(Dh[k], d[k], sd); });
+      static_for<qc>([&](auto KK) { r_h = fmad(Wr[KK], d[KK], r_h); });
+      r_h = (pos_h >= 0) ? r_h : 0.0;
+      double t1 = INF;
+      bool have_t1 = false;
+      if (qc > 0) {
+        double key = (pos_h >= 0 && r_h > 0.0) ? hex_pack_key(u_h * fast_rcp(r_h), h) : HEX_NONE;
+        key = qo.min16(key);
+        have_t1 = key < 1e299;
+        t1 = have_t1 ? key : INF;
+      }
+      const bool dependent = !(d2n > 1e-22 * dnx);
+      const double t2 = -spx * fast_rcp(d2n);
+      const bool full = !dependent && (!have_t1 || !(t1 < t2));
+      if (qo.wave_any(!done && !full) || WBC_GI_FORCE_BAIL(qc)) { stop = true; return; }   // not an add-with-full-step everywhere: generic loop, state untouched
+      if (!done) {
+        iters++;
+        WBC_GI_STAT(if (h == 0) g_gi_fast_trips++);
+        u_h = fmad(-t2, r_h, u_h);
+        z = fmad(t2, zd, z);
+        sh_ = fmad(t2, sd, sh_);
+        // one Householder reflection on d[qc:] (H d2 = alpha e_qc), applied to the own row of J and to the image
+        const double dq = d[qc];
+        const double nrm = fast_sqrt(d2n);
+        const double alpha = (dq > 0.0) ? -nrm : nrm;
+        const double ia = fast_rcp(alpha);
+        const double beta = fast_rcp(nrm * (nrm + fabs(dq)));   // 2 / (v'v)
+        const double vq = dq - alpha;
+        const double w = fmad(-alpha, Jr[qc], zd) * beta, wd = fmad(-alpha, Dh[qc], sd) * beta;   // x . v = x . d[qc:] - alpha x_qc
+        Jr[qc] = fmad(-w, vq, Jr[qc]);
+        Dh[qc] = fmad(-wd, vq, Dh[qc]);
+        static_for<NZ - qc - 1>([&](auto KK) { constexpr int k = qc + 1 + KK; Jr[k] = fmad(-w, d[k], Jr[k]); Dh[k] = fmad(-wd, d[k], Dh[k]); });
+        const bool mine = (h == pf);
+        Wr[qc] = mine ? ia : -r_h * ia;
+        u_h = mine ? t2 : u_h;
+        pos_h = mine ? qc : pos_h;
+        active |= (1ull << pf);
+        q = qc + 1;
+      }
+    });
+  }
+  if (generic) {
+#pragma unroll
+    for (int k = 0; k < NV; k++) { eq[k] = (k == q) ? 1.0 : 0.0; mk[k] = (k >= q) ? 1.0 : 0.0; }
+  }
+  for (int trip = 0; generic && trip < maxit; trip++) {
     if (!done && need_pick) {
       // most violated inactive row: argmin of the tracked values (friction slot: index h, torque slot: 16 + h)
       {
@@ -198,7 +303,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
           // robots of a trot batch (max 7 -> 6, rows needing >= 5: 88 -> 32 of 4096), more for the 4-contact ID stand
           double dd2 = 0.0;
 #pragma unroll
-          for (int k = 0; k < NV; k++) dd2 += mk[k] * Dh[k] * Dh[k];
+          for (int k = 0; k < NV; k++) dd2 = fmad(mk[k] * Dh[k], Dh[k], dd2);
           // a violated row whose image has no free part (linearly dependent on the active ones) must still be
           // picked -- the dependent-step logic below resolves or reports it -- so it gets the largest finite gain
           if (ct && !((active >> h) & 1ull) && sh_ < -tol)
@@ -215,7 +320,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         sp = key;
         p = (key < 1e299) ? ((ix < 16) ? ix : 16 + ix) : -1;   // torque slot ids are 32 + lane
         if (p < 0) sp = INF;
-        if (GAIN && p >= 0 && p < 16) sp = qo.bcast16d(sh_, p & 15);   // the key was the gain, not the value
+        if (p >= 0 && p < 16) sp = qo.bcast16d(sh_, p & 15);   // the exact value (the key carries index bits, or is the gain)
       }
       if (pc && !((active >> 16) & 1ull) && spc < sp) { sp = spc; p = 16; }
       if (!(sp < -tol)) p = -1;
@@ -232,19 +337,20 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     if (qo.wave_all(done)) break;
     if (done) continue;
     iters++;
+    WBC_GI_STAT(if (h == 0) g_gi_generic_trips++);
     double d[NV], dm[NV], d2n = 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       d[k] = TB ? sgp * qo.bcast16d((p >= 32) ? Dt[k] : Dh[k], p & 15) : qo.bcast16d(Dh[k], p & 15);
       if (PC) d[k] = (p == 16) ? Dpc[k] : d[k];
       dm[k] = d[k] * mk[k];
-      d2n += dm[k] * dm[k];
+      d2n = fmad(dm[k], dm[k], d2n);
     }
     double zd = 0.0, sd = 0.0, sdpc = 0.0, sdt = 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-      zd += Jr[k] * dm[k];
-      sd += Dh[k] * dm[k];
+      zd = fmad(Jr[k], dm[k], zd);
+      sd = fmad(Dh[k], dm[k], sd);
       if (PC) sdpc += Dpc[k] * dm[k];
       if (TB) sdt += Dt[k] * dm[k];
     }
@@ -253,7 +359,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     double r_h = 0.0, r_pc = 0.0, r_t = 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-      r_h += Wr[k] * d[k];
+      r_h = fmad(Wr[k], d[k], r_h);
       if (PC) r_pc += Wpc[k] * d[k];
       if (TB) r_t += Wt[k] * d[k];
     }
@@ -286,14 +392,14 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     if (dependent && !have_t1) { status = ST_SINGULAR; done = true; continue; }
     const bool full = !dependent && (!have_t1 || !(t1 < t2));
     const double t = full ? t2 : t1;
-    u_h -= t * r_h;
+    u_h = fmad(-t, r_h, u_h);
     if (PC) u_pc -= t * r_pc;
     if (TB) u_t -= t * r_t;
     up += t;
     {
       const double tz = dependent ? 0.0 : t;
-      z += tz * zd;
-      sh_ += tz * sd;
+      z = fmad(tz, zd, z);
+      sh_ = fmad(tz, sd, sh_);
       if (PC) spc += tz * sdpc;
       if (TB) yt += tz * sdt;
       sp += tz * d2n;
@@ -309,21 +415,23 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       const double vq = dq - alpha;
       const double ia = fast_rcp(alpha);
       const double beta = fast_rcp(nrm * (nrm + fabs(dq)));   // 2 / (v'v)
-      double w = 0.0, wd = 0.0, wp = 0.0, wt = 0.0;
+      // x . v = x . d[q:] - alpha x_q (the dots with d[q:] are zd, sd ... already; x_q picked by the one-hot mask)
+      double jq = 0.0, dhq = 0.0, dpq = 0.0, dtq = 0.0;
       double hv[NV];
 #pragma unroll
       for (int k = 0; k < NV; k++) {
-        hv[k] = dm[k] - alpha * eq[k];   // entry q: dq - alpha = vq
-        w += Jr[k] * hv[k];
-        wd += Dh[k] * hv[k];
-        if (PC) wp += Dpc[k] * hv[k];
-        if (TB) wt += Dt[k] * hv[k];
+        hv[k] = fmad(-alpha, eq[k], dm[k]);   // entry q: dq - alpha = vq
+        jq = fmad(eq[k], Jr[k], jq);
+        dhq = fmad(eq[k], Dh[k], dhq);
+        if (PC) dpq += eq[k] * Dpc[k];
+        if (TB) dtq += eq[k] * Dt[k];
       }
-      w *= beta; wd *= beta; wp *= beta; wt *= beta;
+      const double w = fmad(-alpha, jq, zd) * beta, wd = fmad(-alpha, dhq, sd) * beta;
+      const double wp = PC ? (sdpc - alpha * dpq) * beta : 0.0, wt = TB ? (sdt - alpha * dtq) * beta : 0.0;
 #pragma unroll
       for (int k = 0; k < NV; k++) {
-        Jr[k] -= w * hv[k];
-        Dh[k] -= wd * hv[k];
+        Jr[k] = fmad(-w, hv[k], Jr[k]);
+        Dh[k] = fmad(-wd, hv[k], Dh[k]);
         if (PC) Dpc[k] -= wp * hv[k];
         if (TB) Dt[k] -= wt * hv[k];
       }
@@ -332,7 +440,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       {
         const double wq = mine ? ia : -r_h * ia;
 #pragma unroll
-        for (int k = 0; k < NV; k++) Wr[k] += eq[k] * wq;   // slot q is zero beforehand
+        for (int k = 0; k < NV; k++) Wr[k] = fmad(eq[k], wq, Wr[k]);   // slot q is zero beforehand
       }
       u_h = mine ? up : u_h;
       pos_h = mine ? q : pos_h;
@@ -361,6 +469,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       continue;
     }
     // partial / pure dual step: drop the active row hd (list position ld)
+    WBC_GI_STAT(if (h == 0) g_gi_drops++);
     {
       int ld = qo.bcast16d_i((TB && hd >= 32) ? pos_t : pos_h, hd & 15);
       if (PC) ld = (hd == 16) ? pos_pc : ld;
@@ -485,10 +594,17 @@ template <int NR> WBC_HD double solve6np(double (*Ab)[6 + NR]) {
 // exposed L2 round trip (~0.4 us measured, profiles/r02), an LDS read ~100 cycles.  All 16 lanes
 // write the same value to the same address.  Host: a plain array.
 enum { PK_GS = 0, PK_N = 36 };
+// Lane-private park (lput / lget): what only the output stage needs again (own rows of the torque map, own column of
+// B, the metrics ...) leaves the registers for the QR and the active set -- one ds_write_b64 / ds_read_b64 per double
+// instead of the two v_accvgpr_write + two v_accvgpr_read the register allocator spends on a value it keeps in an
+// AGPR, and ~70 fewer live registers in the two hottest phases (profiles/r02/hex_cuts.md).
+enum { LP_YROW = 0, LP_DROW = 6, LP_T0 = 9, LP_BCOL = 10, LP_AB0 = 16, LP_JIC = 22, LP_RF = 25, LP_BC = 28, LP_MET = 31, LP_N = 36 };
 struct ParkHost {
-  double d[PK_N];
+  double d[PK_N], l[LP_N];
   void put(int i, double v) { d[i] = v; }
   double get(int i) const { return d[i]; }
+  void lput(int i, double v) { l[i] = v; }
+  double lget(int i) const { return l[i]; }
 };
 
 // Diagnostic builds only (-DWBC_HCUT=k): return after phase k with the live values folded into the
@@ -1007,6 +1123,49 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   }
   WBC_HCUT_AT(4, Acol[0] + Acol[5] + Acol[P1 - 1] + Rcol[0] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   level2_rows(Acol + P1);
+  // ---------------- what the friction phase itself needs of the end-of-tick data (torque box, PC row) ...
+  double Tn[NZ], t0n = 0.0, bt = -1.0;   // torque box: own row of the torque map tau = T z + t0' (t0' = t0_own + Y_row.ab0), normalised
+  if (TB) {
+    double n2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < NZ; c++) {
+      const int src = hex_lane(c);
+      double tc = (c / 3 == l) ? Drow[c % 3] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) tc += Yrow[k] * qo.bcast16(bcol[k], src);
+      Tn[c] = tc;
+      n2 += tc * tc;
+    }
+    double t0p = t0_own;
+#pragma unroll
+    for (int k = 0; k < 6; k++) t0p += Yrow[k] * ab0[k];
+    const double inrm = (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0;
+#pragma unroll
+    for (int c = 0; c < NZ; c++) Tn[c] *= inrm;
+    t0n = t0p * inrm;
+    bt = (colv && n2 > 0.0) ? P.tau_max * inrm : -1.0;
+  }
+  const double pc_vr = colv ? vrow_own : 0.0, pc_c = vconst + met_Vdot;
+  double pc_inv = 0.0;
+  if (KIND == KIND_PC) {
+    const double n2 = qo.sum16(pc_vr * pc_vr);
+    pc_inv = (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0;
+  }
+  // ... and the rest waits in the lane's LDS slots until the output stage
+#ifndef WBC_NO_LANEPARK
+  {
+    for (int k = 0; k < 6; k++) { pk.lput(LP_YROW + k, Yrow[k]); pk.lput(LP_BCOL + k, bcol[k]); pk.lput(LP_AB0 + k, ab0[k]); }
+    for (int k = 0; k < 3; k++) {
+      pk.lput(LP_DROW + k, Drow[k]);
+      pk.lput(LP_JIC + k, pick3(sb, Ji[k], Ji[3 + k], Ji[6 + k]));
+      pk.lput(LP_RF + k, rf[k]);
+      pk.lput(LP_BC + k, bc[k]);
+    }
+    pk.lput(LP_T0, t0_own);
+    pk.lput(LP_MET + 0, vrow_own); pk.lput(LP_MET + 1, vconst); pk.lput(LP_MET + 2, met_V);
+    pk.lput(LP_MET + 3, met_Vdot); pk.lput(LP_MET + 4, met_err);
+  }
+#endif
   hex_qr_append<Q, P1 + NZ, NV>(qo, Rcol, Acol);
   WBC_HCUT_AT(5, Rcol[0] + Rcol[5] + Rcol[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- own row of J = R^-1 and unconstrained minimiser
@@ -1059,33 +1218,9 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   int iters = 0;
   {
     const double s = sqrt(1.0 + mu * mu);
-    // torque box: own row of the torque map tau = T z + t0' (t0' = t0_own + Y_row.ab0), normalised
-    double Tn[NZ], t0n = 0.0, bt = -1.0;
-    if (TB) {
-      double n2 = 0.0;
-#pragma unroll
-      for (int c = 0; c < NZ; c++) {
-        const int src = hex_lane(c);
-        double tc = (c / 3 == l) ? Drow[c % 3] : 0.0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) tc += Yrow[k] * qo.bcast16(bcol[k], src);
-        Tn[c] = tc;
-        n2 += tc * tc;
-      }
-      double t0p = t0_own;
-#pragma unroll
-      for (int k = 0; k < 6; k++) t0p += Yrow[k] * ab0[k];
-      const double inrm = (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0;
-#pragma unroll
-      for (int c = 0; c < NZ; c++) Tn[c] *= inrm;
-      t0n = t0p * inrm;
-      bt = (colv && n2 > 0.0) ? P.tau_max * inrm : -1.0;
-    }
     int st;
     if (KIND == KIND_PC) {
-      const double vr = colv ? vrow_own : 0.0;
-      const double n2 = qo.sum16(vr * vr);
-      st = hex_gi<Q, true, NV, TB, false>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, vr, vconst + met_Vdot, (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0, Tn, t0n, bt);
+      st = hex_gi<Q, true, NV, TB, false>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt);
     } else if (KIND == KIND_CLF) {
       // the CLF row  g . [z; delta] - ub <= 0  is the dense row of the active set (index 16), like PC's Vdot row
       st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt);
@@ -1097,6 +1232,20 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   *iters_out = iters;
   WBC_HCUT_AT(7, z + (double)iters + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- outputs: a_b = ab0 + sum B z ;  tau_(l,j) = Y_l[j] a_b + D_l[j] z_l + t0_l[j]
+  double jic[3];
+#ifndef WBC_NO_LANEPARK
+  {
+    for (int k = 0; k < 6; k++) { Yrow[k] = pk.lget(LP_YROW + k); bcol[k] = pk.lget(LP_BCOL + k); ab0[k] = pk.lget(LP_AB0 + k); }
+    for (int k = 0; k < 3; k++) { Drow[k] = pk.lget(LP_DROW + k); jic[k] = pk.lget(LP_JIC + k); rf[k] = pk.lget(LP_RF + k); }
+    t0_own = pk.lget(LP_T0);
+    vrow_own = pk.lget(LP_MET + 0); vconst = pk.lget(LP_MET + 1); met_V = pk.lget(LP_MET + 2);
+    met_Vdot = pk.lget(LP_MET + 3); met_err = pk.lget(LP_MET + 4);
+  }
+  const double bcp[3] = {pk.lget(LP_BC + 0), pk.lget(LP_BC + 1), pk.lget(LP_BC + 2)};
+#else   // A/B build: everything stays in registers / AGPRs
+  for (int k = 0; k < 3; k++) jic[k] = pick3(sb, Ji[k], Ji[3 + k], Ji[6 + k]);
+  const double bcp[3] = {bc[0], bc[1], bc[2]};
+#endif
   const double z0 = qo.leg_bcast(z, 0), z1 = qo.leg_bcast(z, 1), z2 = qo.leg_bcast(z, 2);
   {
     double ab[6];
@@ -1111,8 +1260,8 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     double t[3], y[3];
     cross(ab, rf, t);
     const double zl[3] = {z0, z1, z2};
-    for (int i = 0; i < 3; i++) y[i] = (ct ? bc[i] : zl[i]) - (ab[3 + i] + t[i]);
-    const double qdd = pick3(sb, Ji[0], Ji[3], Ji[6]) * y[0] + pick3(sb, Ji[1], Ji[4], Ji[7]) * y[1] + pick3(sb, Ji[2], Ji[5], Ji[8]) * y[2];
+    for (int i = 0; i < 3; i++) y[i] = (ct ? bcp[i] : zl[i]) - (ab[3 + i] + t[i]);
+    const double qdd = jic[0] * y[0] + jic[1] * y[1] + jic[2] * y[2];
     if (colv) out_met(4 + 6 + m.q_perm[3 * l + sb], sing ? 0.0 : qdd);
   }
   double res = 0.0;

@@ -170,18 +170,22 @@ struct HexDev {
     return x;
   }
   __device__ __forceinline__ double sum16(double x) const { return legs_sum(leg_sum(x)); }
+  // v_min_f64 / v_max_f64 through asm: fmin()/fmax() first canonicalise both operands (a v_max_f64 x, x, x each), which
+  // only matters for signalling NaNs -- the keys here are never NaN (HEX_NONE is finite)
+  static __device__ __forceinline__ double vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+  static __device__ __forceinline__ double vmax(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
   __device__ __forceinline__ double min16(double x) const {
-    x = fmin(x, dpp<0xB1>(x));
-    x = fmin(x, dpp<0x4E>(x));
-    x = fmin(x, dpp<0x128>(x));
-    x = fmin(x, dpp<0x124>(x));
+    x = vmin(x, dpp<0xB1>(x));
+    x = vmin(x, dpp<0x4E>(x));
+    x = vmin(x, dpp<0x128>(x));
+    x = vmin(x, dpp<0x124>(x));
     return x;
   }
   __device__ __forceinline__ double max16(double x) const {
-    x = fmax(x, dpp<0xB1>(x));
-    x = fmax(x, dpp<0x4E>(x));
-    x = fmax(x, dpp<0x128>(x));
-    x = fmax(x, dpp<0x124>(x));
+    x = vmax(x, dpp<0xB1>(x));
+    x = vmax(x, dpp<0x4E>(x));
+    x = vmax(x, dpp<0x128>(x));
+    x = vmax(x, dpp<0x124>(x));
     return x;
   }
   __device__ __forceinline__ bool any16(bool b) const {
@@ -193,6 +197,7 @@ struct HexDev {
     return x != 0;
   }
   __device__ __forceinline__ bool wave_all(bool b) const { return __all(b); }
+  __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }
   __device__ __forceinline__ int wave_max_int(int x) const {
     int m = 0;
 #pragma unroll
@@ -211,12 +216,15 @@ constexpr int HROBOTS = HEX_BLOCK / 16;    // robots per workgroup
 // ordinary, schedulable LDS loads
 struct ParkLds {
   double* a;
+  double* la;   // lane-private slots: element i of this lane at la[i * HEX_BLOCK] (consecutive lanes = consecutive banks)
   int z;  // an opaque zero: reads go through a[z + i], which the compiler can neither forward from the stores
           // nor demote to a generic (flat) access -- laundering the POINTER loses the LDS address space and
           // turns every read into a flat_load with vmcnt waits (measured, profiles/r01/hex_cuts.md)
-  __device__ __forceinline__ explicit ParkLds(double* p) : a(p), z(0) { asm volatile("" : "+v"(z)); }
+  __device__ __forceinline__ ParkLds(double* p, double* lp) : a(p), la(lp), z(0) { asm volatile("" : "+v"(z)); }
   __device__ __forceinline__ void put(int i, double v) { a[i] = v; }
   __device__ __forceinline__ double get(int i) const { return a[z + i]; }
+  __device__ __forceinline__ void lput(int i, double v) { la[i * HEX_BLOCK] = v; }
+  __device__ __forceinline__ double lget(int i) const { return la[z + i * HEX_BLOCK]; }
 };
 
 #ifndef WBC_HEX_WAVES_PER_EU
@@ -234,7 +242,17 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   __shared__ double mbuf[MPER * HEX_BLOCK];
   __shared__ double inbuf[PER_LANE * HEX_BLOCK];                      // 91 rows x 4 robots, padded to whole lanes
   __shared__ double parkbuf[HROBOTS * wbc::PK_N];
+  __shared__ double lanebuf[wbc::LP_N * HEX_BLOCK];
   WBC_STAMP(0);
+#ifdef WBC_STAMPS   // where this wavefront runs: HW_ID (cu / simd / se) and XCC_ID
+  if (threadIdx.x == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_wbc_stamps[(size_t)blockIdx.x * 16 + 8] = hw;
+    g_wbc_stamps[(size_t)blockIdx.x * 16 + 9] = xcc;
+  }
+#endif
   const int slot = threadIdx.x >> 4;
   const int i = blockIdx.x * HROBOTS + slot;
   const bool live = i < n;
@@ -293,7 +311,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   volatile double junk[WBC_FORCE_SCRATCH];
   for (int k = 0; k < WBC_FORCE_SCRATCH; k++) junk[k] = inbuf[k];
 #endif
-  ParkLds park(parkbuf + slot * wbc::PK_N);
+  ParkLds park(parkbuf + slot * wbc::PK_N, lanebuf + threadIdx.x);
   const int st = wbc::hex_tick<HexDev, KIND, TB>(m, P, qo, in, mk, mui, msi, park, ot, om, &iters);
 #ifdef WBC_FORCE_SCRATCH
   if (junk[threadIdx.x % WBC_FORCE_SCRATCH] == 1.2345e300) iters++;
@@ -338,6 +356,7 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* _
   __shared__ double mbuf[MPER * HEX_BLOCK];
   __shared__ double inbuf[PER_LANE * HEX_BLOCK];
   __shared__ double parkbuf[HROBOTS * wbc::PK_N];
+  __shared__ double lanebuf[wbc::LP_N * HEX_BLOCK];
   __shared__ double vdbuf[HROBOTS * 18];
   __shared__ double outbuf[HROBOTS * 18];
   __shared__ double robuf[HROBOTS * 4];     // per robot: time, lookup hint, mu, mass scale (loop-carried, kept out of registers)   // last tick: tau (12), metrics (4), status, mask -- written to HBM once, after the loop
@@ -366,7 +385,7 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* _
   }
   __syncthreads();
   auto in = [&](int r) -> double { return inbuf[r * HROBOTS + slot]; };
-  ParkLds park(parkbuf + slot * wbc::PK_N);
+  ParkLds park(parkbuf + slot * wbc::PK_N, lanebuf + threadIdx.x);
   for (int step = 0; step < steps; step++) {
     // The model table and the parameters are loop-invariant, and the compiler would hoist ~130 doubles of them out
     // of the step loop into registers (the kernel then spills): an opaque zero offset per iteration keeps those
@@ -660,6 +679,13 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
   h->last_variant = 3;
   StatsDev* d_stats = getenv("WBC_NO_STATS") ? nullptr : h->d_stats;  // diagnostic switch
   dim3 grid((n + HROBOTS - 1) / HROBOTS);
+#ifdef WBC_DEV_ONLY   // diagnostic builds (tools/build_cuts.sh): ONE law instantiated, seconds to compile
+  if (h->kind != WBC_DEV_ONLY || h->torque_box) return misuse("this diagnostic build carries one law only (WBC_DEV_ONLY)");
+  hipLaunchKernelGGL((wbc_hex_kernel<WBC_DEV_ONLY, false>), grid, dim3(HEX_BLOCK), 0, h->stream, h->d_model, h->d_params, n, ld, q, v,
+                     tg, mask, mu, ms, tau, met, status, d_stats, h->d_vdot);
+  HIP_TRY(hipGetLastError());
+  return 0;
+#else
 #define WBC_HEX_ARGS grid, dim3(HEX_BLOCK), 0, h->stream, h->d_model, h->d_params, n, ld, q, v, tg, mask, mu, ms, tau, met, status, d_stats, h->d_vdot
   if (h->torque_box) {   // second constraint slot per lane: |tau_j| <= tau_max (wbc_hex.hpp)
     switch (h->kind) {
@@ -679,6 +705,7 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
 #undef WBC_HEX_ARGS
   HIP_TRY(hipGetLastError());
   return 0;
+#endif
 }
 
 static int check_step_args(wbc_handle h, int n, int ld, const void* q, const void* v, const void* tg,
@@ -833,6 +860,9 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
   if (h->flags & WBC_HOST_PTRS) return misuse("wbc_rollout: needs a WBC_DEVICE_PTRS handle");
   if (steps == 0 || n == 0) return 0;
   HIP_TRY(hipSetDevice(h->device));
+#ifdef WBC_DEV_ONLY
+  return misuse("wbc_rollout: not part of a WBC_DEV_ONLY diagnostic build");
+#else
   {
     // the whole rollout is ONE persistent launch per <= 1024 ticks (wbc_hex_rollout_kernel)
     wbc::TrajDev T;
@@ -860,6 +890,7 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
     HIP_TRY(hipGetLastError());
     return 0;
   }
+#endif
 }
 
 int wbc_set_variant(wbc_handle h, int variant) {
@@ -879,6 +910,9 @@ int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_by
   if (!h) return misuse("wbc_kernel_info: null handle");
   hipFuncAttributes a;
   const void* fn;
+#ifdef WBC_DEV_ONLY
+  fn = (const void*)wbc_hex_kernel<WBC_DEV_ONLY, false>;
+#else
   if (h->torque_box)
     fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID, true>
        : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_kernel<wbc::KIND_MPTC, true>
@@ -887,6 +921,7 @@ int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_by
     fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_kernel<wbc::KIND_ID>
        : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_kernel<wbc::KIND_MPTC>
        : h->kind == WBC_KIND_PC ? (const void*)wbc_hex_kernel<wbc::KIND_PC> : (const void*)wbc_hex_kernel<wbc::KIND_CLF>;
+#endif
   HIP_TRY(hipFuncGetAttributes(&a, fn));
   if (num_vgpr) *num_vgpr = a.numRegs;
   if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;

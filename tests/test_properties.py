@@ -5,7 +5,7 @@ GPU (-m gpu): the device outputs, with the contact forces RECOVERED from (tau, v
 terms (M vd + Cv + tau_g = S'tau + sum J_c' f, basic_controller.py:106), so nothing of the kernel's own algebra is reused."""
 import numpy as np
 import pytest
-from hypothesis import HealthCheck, given, settings, strategies as st
+from hypothesis import HealthCheck, assume, given, settings, strategies as st
 
 import host_tick as ht
 from oracle import oracle_py as orc
@@ -53,6 +53,8 @@ def test_oracle_solution_satisfies_the_reference_rows(seed, mask, kind, mu, scal
     m = orc.model("mini_cheetah"); p = orc.params(kind); p.mu = mu
     ct = [(mask >> k) & 1 for k in range(4)]
     tau, met, stt, qp = orc.control_law(kind, m, p, b["q"][:, 0], b["v"][:, 0], b["targets"][:, 0], ct, want_qp=True)
+    if kind == "pc" and stt == 2:
+        assume(False)      # the PC law's hard row Vdot <= 0 can be infeasible under the friction limits (the reference asserts there)
     assert stt == 0
     x = qp["x"]
     sc = 1.0 + np.abs(x).max()
@@ -82,6 +84,9 @@ def test_kernel_math_matches_oracle_and_is_batch_position_invariant(seed, mask, 
     q[:, pos] = b["q"][:, 0]; v[:, pos] = b["v"][:, 0]; tg[:, pos] = b["targets"][:, 0]; mk[pos] = mask
     tau, met, stt, _ = ht.run(kind, t["flat"], q, v, tg, mk, params12=pp, hexv=True)
     tau1, met1, st1, _ = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], params12=pp, hexv=True)
+    if kind == "pc" and st_o == 2:
+        assert stt[pos] == 2           # infeasible passivity row: both report it
+        return
     assert st_o == 0 and stt[pos] == 0
     assert np.array_equal(tau[:, pos], tau1[:, 0]) and np.array_equal(met[:, pos], met1[:, 0])
     assert np.abs(tau[:, pos] - tau_o).max() < 1e-4 * max(np.abs(tau_o).max(), 1e-3)
@@ -117,8 +122,11 @@ def test_gpu_outputs_satisfy_dynamics_and_friction(seed, kind, mu, scale):
     ctrl.set_vdot_output(None)
     ctrl.close()
     m = orc.model("mini_cheetah")
-    assert (stn == 0).all()
+    if kind != "pc":
+        assert (stn == 0).all()
     for i in range(n):
+        if stn[i] != 0:
+            continue                   # PC: an infeasible passivity row is reported (zero torques), nothing to check
         f, base = recover_forces(m, q[:, i], v[:, i], tau[:, i], vdn[:, i], int(mk[i]))
         sc = 1.0 + np.abs(tau[:, i]).max() + np.abs(f).max()
         assert np.abs(base).max() < 1e-7 * sc, (i, masks[i], np.abs(base).max())          # base rows of the dynamics close

@@ -122,6 +122,13 @@ int host_tick_count(int kind, const double* flat215, const double* params12, int
 // "publish, barrier, read, barrier".  The reductions use the association of the device butterflies
 // (quad_perm xor 1, xor 2, then row_ror:8, row_ror:4), so replicated values are bit-identical.
 #include <ucontext.h>
+#define WBC_HOST_GI_STATS 1
+int g_gi_fast_trips = 0, g_gi_generic_trips = 0, g_gi_drops = 0, g_gi_force_bail = -1;
+extern "C" void host_gi_force_bail(int qc) { g_gi_force_bail = qc; }   // tests: leave the fast path at trip qc (a wave-mate's drop)
+extern "C" void host_gi_stats(int* out, int reset) {
+  out[0] = g_gi_fast_trips; out[1] = g_gi_generic_trips; out[2] = g_gi_drops;
+  if (reset) g_gi_fast_trips = g_gi_generic_trips = g_gi_drops = 0;
+}
 #include "../quadruped_drake_amd/csrc/wbc_hex.hpp"
 
 namespace {
@@ -243,6 +250,7 @@ struct HexHost {
     v = bv; i = bi;
   }
   bool wave_all(bool b) { return b; }
+  bool wave_any(bool b) { return b; }
   int wave_max_int(int x) { return x; }
 };
 

@@ -24,3 +24,20 @@ tot = t[:, 5] - t[:, 0]
 print("wave lifetime first->last stamp: p10 %d p50 %d p90 %d p99 %d max %d cycles" % tuple(np.percentile(tot, [10, 50, 90, 99, 100])))
 print("first stamp spread across blocks (launch skew): p10 %d p50 %d p90 %d max %d cycles" % tuple(np.percentile(t[:, 0] - t[:, 0].min(), [10, 50, 90, 100])))
 print("last stamp - earliest first stamp: %d cycles" % (t[:, 5].max() - t[:, 0].min()))
+
+# placement: how many wavefronts share a (xcc, se, cu, simd) and when the late ones start
+hw = buf[:, 8].astype(np.int64); xcc = buf[:, 9].astype(np.int64) & 0xF
+simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+key = ((xcc * 8 + se) * 2 + sh) * 16 * 4 + cu * 4 + simd
+u, cnt = np.unique(key, return_counts=True)
+print("distinct SIMDs used: %d of %d wavefronts; wavefronts per SIMD histogram: %s" % (u.size, nb, np.bincount(cnt).tolist()))
+cukey = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+u2, c2 = np.unique(cukey, return_counts=True)
+print("distinct CUs used: %d; wavefronts per CU histogram: %s" % (u2.size, np.bincount(c2).tolist()))
+t0 = t[:, 0] - t[:, 0].min(); t5 = t[:, 5] - t[:, 0].min()
+print("starts after the earliest finish (second-round wavefronts): %d" % int((t0 > t5.min()).sum()))
+print("start percentiles p50 %d p90 %d p99 %d max %d ; end percentiles p1 %d p50 %d p90 %d p99 %d max %d" % (
+    tuple(np.percentile(t0, [50, 90, 99, 100])) + tuple(np.percentile(t5, [1, 50, 90, 99, 100]))))
+late = np.argsort(-t5)[:8]
+print("latest finishers: block, start, end, lifetime, xcc, se, cu, simd")
+for i in late: print("  ", i, t0[i], t5[i], tot[i], xcc[i], se[i], cu[i], simd[i])
