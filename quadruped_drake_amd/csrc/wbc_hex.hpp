@@ -566,7 +566,7 @@ template <int NR> WBC_HD double solve6np(double (*Ab)[6 + NR]) {
     const double best = fabs(Ab[c][c]);
     if (c == 0 || best < pmin) pmin = best;
     if (best > pmax) pmax = best;
-    const double id = 1.0 / Ab[c][c];
+    const double id = fast_rcp(Ab[c][c]);
 #pragma unroll
     for (int j = c + 1; j < 6 + NR; j++) Ab[c][j] *= id;   // row c scaled: unit diagonal
 #pragma unroll
@@ -643,7 +643,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   double R0[9];
   {
     const double qw = in(0), qx = in(1), qy = in(2), qz = in(3);
-    const double s = 2.0 / (qw * qw + qx * qx + qy * qy + qz * qz);
+    const double s = 2.0 * fast_rcp(qw * qw + qx * qx + qy * qy + qz * qz);
     R0[0] = 1.0 - s * (qy * qy + qz * qz); R0[1] = s * (qx * qy - qw * qz); R0[2] = s * (qx * qz + qw * qy);
     R0[3] = s * (qx * qy + qw * qz); R0[4] = 1.0 - s * (qx * qx + qz * qz); R0[5] = s * (qy * qz - qw * qx);
     R0[6] = s * (qx * qz - qw * qy); R0[7] = s * (qy * qz + qw * qx); R0[8] = 1.0 - s * (qx * qx + qy * qy);
@@ -669,7 +669,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       const double ang = atan2(pick3(sb, R0[7], -R0[6], R0[3]), pick3(sb, R0[8], cp, R0[0]));
       rpy[0] = qo.leg_bcast(ang, 0); rpy[1] = qo.leg_bcast(ang, 1); rpy[2] = qo.leg_bcast(ang, 2);
     }
-    const double icp = 1.0 / cp;
+    const double icp = fast_rcp(cp);
     const double cy = R0[0] * icp, sy = R0[3] * icp;
     E[0] = cp * cy; E[1] = -sy; E[2] = 0.0; E[3] = cp * sy; E[4] = cy; E[5] = 0.0; E[6] = -sp; E[7] = 0.0; E[8] = 1.0;
     const double Ei[9] = {cy * icp, sy * icp, 0.0, -sy, cy, 0.0, cy * sp * icp, sy * sp * icp, 1.0};
@@ -731,8 +731,9 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
         double so, co;
         wbc_sincos(pick3(sb, th[0], th[1], th[2]), so, co);
         for (int k = 0; k < 3; k++) { sn[k] = qo.leg_bcast(so, k); cs[k] = qo.leg_bcast(co, k); }
+        if ((KIND == KIND_ID || KIND == KIND_CLF) && !ct) knee_clamp(sn[2], cs[2]);   // swing legs of the ID-type laws (wbc_tick.hpp)
       }
-      leg_fk_vec(m, l, R0, sn, cs, K);
+      leg_fk_xyy(m, l, R0, sn, cs, K);
     }
     leg_crba(mass3, K, D, lm, lh, lI);
     for (int i = 0; i < 3; i++) rf[i] = K.rf(i);
@@ -743,7 +744,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       cross(axv, d, c);
       for (int i = 0; i < 3; i++) Jl[3 * i + k] = c[i];
     }
-    const double det = inv3(Jl, Ji);
+    const double det = inv3_fast(Jl, Ji);
     if (qo.any16(!(fabs(det) > 1e-12))) status = ST_SINGULAR;
     double Mf[9];
     sym_to_full(D.Mll, Mf);
@@ -767,7 +768,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     }
     if (MP) {
       double Mli[9];
-      inv3(Mf, Mli);
+      inv3_fast(Mf, Mli);
       double t[3], jfb[3];
       cross(xdt_b, rf, t);
       for (int i = 0; i < 3; i++) jfb[i] = xdt_b[3 + i] + t[i];
@@ -1006,7 +1007,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     {
       double Mf[9], Mli[9];
       sym_to_full(Mll6, Mf);
-      inv3(Mf, Mli);
+      inv3_fast(Mf, Mli);
       for (int i = 0; i < 3; i++)
         for (int j = 0; j < 6; j++) MiY[6 * i + j] = Mli[3 * i] * Y[j] + Mli[3 * i + 1] * Y[6 + j] + Mli[3 * i + 2] * Y[12 + j];
     }

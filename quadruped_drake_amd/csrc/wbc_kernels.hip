@@ -585,6 +585,9 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
   if (max_batch <= 0) return misuse("wbc_create: max_batch must be positive");
   wbc::ModelC m;
   if (wbc::model_from_flat(model->flat, &m)) return misuse("wbc_create: joint axes must be axis-aligned");
+  if (!wbc::model_axes_are_xyy(&m))
+    return misuse("wbc_create: unsupported kinematic tree -- the kernels are specialised to legs with the abduction joint "
+                  "about +-x and the hip and knee joints about +-y (Mini Cheetah, ANYmal)");
   bool seen_q[12] = {0}, seen_a[12] = {0};
   for (int i = 0; i < 12; i++) {
     int a = model->q_perm[i], b = model->act_perm[i];

