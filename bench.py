@@ -52,6 +52,8 @@ def parse():
                     help="process-group backend; gloo = CPU test switch (dry run without a GPU)")
     ap.add_argument("--dry-run", action="store_true", help="launch + shard + statistics exchange only, no kernel")
     ap.add_argument("--launch-timeout", type=float, default=1800.0, help="self-launch: seconds before the children are stopped")
+    ap.add_argument("--ramp-seconds", type=float, default=1.0,
+                    help="untimed launches before the W warm-up steps until the GPU holds its sustained clock (DVFS ramp)")
     return ap.parse_args()
 
 
@@ -145,7 +147,7 @@ def cpu_baseline(batch, seconds):
 
     # thread-scaling curve (about 1.5 s each): shows whether the lease really has the cores its affinity mask lists
     curve = {}
-    for th in sorted({1, 2, 4, 8, 64, lim["affinity"]}):
+    for th in sorted({1, 2, 4, 8, 64, cores, lim["affinity"]}):
         if th > lim["affinity"]:
             continue
         r, _ = timed(th, rate1 * 1.5 * min(th, 8))
@@ -164,7 +166,7 @@ def cpu_baseline(batch, seconds):
     t0 = time.perf_counter()
     orc.bench_batch("id", mid, pid, q0, v0, tg0, mk0, nthreads=1, reps=1200)
     c1 = time.perf_counter() - t0
-    return {"value": rate, "unit": "ticks/s", "cores": use, "kind": "port",
+    return {"value": rate, "unit": "ticks/s", "cores": min(use, cores), "threads": use, "kind": "port",
             "single_core_ticks_per_s": rate1, "thread_scaling_ticks_per_s": curve, "host": lim,
             "build": "gcc -O3 -march=x86-64-v3 -fopenmp -ffp-contract=off (oracle/Makefile)",
             "config1": {"workload": "BASELINE configs[0] restated: 1 Mini Cheetah, ID law, q0 of simulate.py:171-176, "
@@ -306,6 +308,11 @@ def run_rank(a):
     out = (torch.empty((12, n), dtype=torch.float64, device=dev), torch.empty((4, n), dtype=torch.float64, device=dev),
            torch.empty((n,), dtype=torch.int32, device=dev))
 
+    # clock ramp: the GPU raises its clock over the first ~1 s of sustained load (measured: 29.4 -> 26.7 us per launch,
+    # profiles/r02/tail_experiment.md); steady state is what a control loop sees, so the ramp is not part of the W + K steps
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < a.ramp_seconds:
+        ctrl.time_steps(100, q, v, tg, mask, mu, ms, out=out)
     for _ in range(a.warmup):
         ctrl.step(q, v, tg, mask, mu, ms, out=out)
     wstats.all_gather_stats(ctrl.stats(), device=cdev)            # warm the statistics exchange (RCCL channel set-up) as well
@@ -348,7 +355,7 @@ def run_rank(a):
             "value": n_total * a.steps / dt, "unit": "ticks/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic", "backend": a.backend,
+            "dtype": "f64", "data": "synthetic", "backend": a.backend, "ramp_seconds": a.ramp_seconds,
             "ranks_seen": seen, "per_rank_ticks": [r["ticks"] for r in per_rank],
             "config": {"workload": "BASELINE configs[%d]: %d x %s, %s controller, %s" % (
                 cfg - 1, n_total, shard["model"], shard["kind"].upper(),

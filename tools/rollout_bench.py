@@ -22,7 +22,7 @@ for cls, dt in ((MPTCController, 1e-3), (IDController, 5e-3)):
     ctrl.rollout(traj, steps, dt, q, v, t); ctrl.sync()
     el = time.perf_counter() - t0
     s = ctrl.stats()
-    print("%s N=%d: %.1f us per closed-loop step, %.1f M ticks/s, status_nonzero=%d" % (cls.__name__, n, el / steps * 1e6, n * steps / el / 1e6, s["status_nonzero"]))
+    print("%s N=%d: %.1f us per closed-loop step, %.1f M ticks/s, status_nonzero=%d, mean iterations %.2f" % (cls.__name__, n, el / steps * 1e6, n * steps / el / 1e6, s["status_nonzero"], s["iters_sum"] / max(s["ticks"], 1)))
     ctrl.close()
 
 
@@ -41,8 +41,8 @@ traj = TrunkTrajectory(ts, tg, masks, wait_time=0.0, device=0, standing_targets=
 q0, v0 = workloads.nominal_state("mini_cheetah", n)
 rng = np.random.default_rng(1)
 q0[7:] += rng.uniform(-0.03, 0.03, (12, n))
-for variant in ("hex", "quad"):
-    ctrl = MPTCController(max_batch=n, device=0); ctrl.set_variant(variant)
+for variant in ("hex",):
+    ctrl = MPTCController(max_batch=n, device=0)
     q = torch.tensor(q0, device="cuda:0"); v = torch.tensor(v0, device="cuda:0")
     t = torch.tensor(rng.uniform(0.0, 0.6, n), device="cuda:0")
     ctrl.rollout(traj, 20, 1e-3, q, v, t); ctrl.sync(); ctrl.stats(reset=True)
