@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend; gloo = CPU test switch (dry run without a GPU)")
     ap.add_argument("--dry-run", action="store_true", help="launch + shard + statistics exchange only, no kernel")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="test switch (with --backend gloo): every rank computes on GPU 0 -- exercises the self-launched N > 1 path on a one-GPU box")
     ap.add_argument("--launch-timeout", type=float, default=1800.0, help="self-launch: seconds before the children are stopped")
     ap.add_argument("--ramp-seconds", type=float, default=1.0,
                     help="untimed launches before the W warm-up steps until the GPU holds its sustained clock (DVFS ramp)")
@@ -220,9 +222,9 @@ def large_batch(device, steps=40):
     args = [up(b[k]) for k in ("q", "v", "targets", "mask", "mu", "mass_scale")]
     out = (torch.empty((12, n), dtype=torch.float64, device=dev), torch.empty((4, n), dtype=torch.float64, device=dev),
            torch.empty((n,), dtype=torch.int32, device=dev))
-    for _ in range(5):
-        ctrl.step(*args, out=out)
-    ctrl.sync()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:          # the clock ramp of the main line, for this batch size
+        ctrl.time_steps(20, *args, out=out)
     ms, _ = ctrl.time_steps(steps, *args, out=out)
     bad = int((out[2] != 0).sum())
     ctrl.close()
@@ -244,6 +246,9 @@ def run_rank(a):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.share_gpu:
+        assert a.backend == "gloo", "--share-gpu is a gloo test switch (RCCL refuses two ranks on one device)"
+        local = 0
     assert world == a.gpus, "WORLD_SIZE must equal --gpus"
     have_gpu = torch.cuda.is_available()
     dry = a.dry_run or (a.backend == "gloo" and not have_gpu)

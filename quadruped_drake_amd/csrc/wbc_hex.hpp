@@ -202,7 +202,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
   for (int k = 0; k < NV; k++) { eq[k] = (k == 0) ? 1.0 : 0.0; mk[k] = 1.0; }
   const int maxit = 200;
-  bool done = false, need_pick = true;
+  bool done = false, need_pick = true, picked = false;
   int p = -1;
   double sp = 0.0, up = 0.0, dnp = 1.0, sgp = 1.0;
   const double INF = __builtin_huge_val();
@@ -215,7 +215,10 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   // needs something else (a partial step = a drop, a dependent row) the trip is abandoned BEFORE it has changed any
   // state and the generic loop below takes over.  Both paths evaluate the same expressions in the same order, so a
   // robot's result does not depend on which path its wavefront took (bit-identical; tests: batch-position invariance).
-  constexpr int QF = (!PC && !TB && NV == NZ) ? 8 : 0;
+#ifndef WBC_QF_ID
+#define WBC_QF_ID 8
+#endif
+  constexpr int QF = (!PC && !TB && NV == NZ) ? (GAIN ? 8 : WBC_QF_ID) : 0;   // ID stands add up to 8-12 rows before the first drop
   bool generic = true;   // wave-uniform: the generic loop still has work to do
   if constexpr (QF > 0) {
     bool stop = false;   // wave-uniform
@@ -320,17 +323,31 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         sp = key;
         p = (key < 1e299) ? ((ix < 16) ? ix : 16 + ix) : -1;   // torque slot ids are 32 + lane
         if (p < 0) sp = INF;
-        if (p >= 0 && p < 16) sp = qo.bcast16d(sh_, p & 15);   // the exact value (the key carries index bits, or is the gain)
       }
+      picked = true;
+    }
+    // ONE round trip through the lane crossbar per trip: the image of the (newly or previously) picked row and, for a new
+    // pick, its exact value (the key carries index bits, or is the gain), its norm and -- torque rows -- its violated side
+    const int pl = (p >= 0 && p != 16) ? (p & 15) : h;
+    const bool trow = TB && p >= 32;
+    double d[NV], dm[NV], d2n = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) d[k] = qo.bcast16d(trow ? Dt[k] : Dh[k], pl);
+    const double sp_x = qo.bcast16d(sh_, pl), dn_x = qo.bcast16d(trow ? dnt : dnh, pl);
+    double sg_x = 1.0;
+    if (TB) sg_x = qo.bcast16d((yt > 0.0) ? -1.0 : 1.0, pl);
+    if (picked) {
+      picked = false;
+      if (p >= 0 && p < 16) sp = sp_x;
       if (pc && !((active >> 16) & 1ull) && spc < sp) { sp = spc; p = 16; }
       if (!(sp < -tol)) p = -1;
       if (p < 0) {
         done = true;
       } else {
         up = 0.0;
-        dnp = qo.bcast16d((TB && p >= 32) ? dnt : dnh, p & 15);
+        dnp = dn_x;
         if (PC) dnp = (p == 16) ? dnpc : dnp;
-        if (TB) sgp = (p >= 32) ? qo.bcast16d((yt > 0.0) ? -1.0 : 1.0, p & 15) : 1.0;   // violated side of a torque row
+        if (TB) sgp = (p >= 32) ? sg_x : 1.0;   // violated side of a torque row
         need_pick = false;
       }
     }
@@ -338,10 +355,9 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     if (done) continue;
     iters++;
     WBC_GI_STAT(if (h == 0) g_gi_generic_trips++);
-    double d[NV], dm[NV], d2n = 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) {
-      d[k] = TB ? sgp * qo.bcast16d((p >= 32) ? Dt[k] : Dh[k], p & 15) : qo.bcast16d(Dh[k], p & 15);
+      if (TB) d[k] = sgp * d[k];
       if (PC) d[k] = (p == 16) ? Dpc[k] : d[k];
       dm[k] = d[k] * mk[k];
       d2n = fmad(dm[k], dm[k], d2n);
@@ -1226,7 +1242,10 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       // the CLF row  g . [z; delta] - ub <= 0  is the dense row of the active set (index 16), like PC's Vdot row
       st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt);
     } else {
-      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC) && !TB>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt);
+#ifndef WBC_GAIN_ID
+#define WBC_GAIN_ID 0
+#endif
+      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC || (WBC_GAIN_ID && KIND == KIND_ID)) && !TB>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt);
     }
     if (st != ST_OK) status = st;
   }

@@ -40,3 +40,19 @@ def test_single_rank_without_gpu_fails_loudly():
         return
     r = _run(["--gpus", "1", "--steps", "1"], timeout=120)
     assert r.returncode != 0 and "no GPU" in (r.stderr + r.stdout)
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_compute_on_the_gpu():
+    """The self-launched N > 1 path with the REAL kernel: two rank processes, contiguous shards of BASELINE config 5's batch,
+    one statistics all-gather -- both ranks share GPU 0 here (gloo test switch; RCCL needs one device per rank)."""
+    r = _run(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "5", "--warmup", "2", "--ramp-seconds", "0", "--per-gpu", "512"],
+             timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert "dry_run" not in d and d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    assert d["per_rank_ticks"] == [512.0 * 5, 512.0 * 5] and d["rollout_stats"]["ticks"] == 2 * 512 * 5
+    assert d["status_nonzero"] == 0 and d["value"] > 0 and d["config"]["domain_randomised"] is True
