@@ -721,6 +721,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       }
     }
   }
+  WBC_STAMP(10);
   WBC_HCUT_AT(1, xt_b[0] + xt_b[4] + xdt_b[1] + xdt_b[5] + xdd_b[2] + ades[1] + bI[3] + bmc[1] + R0[5] + rpyd[0] + E[3])
   // ---------------- own leg (replicated on its four sub-lanes unless noted)
   double rf[3], Jdv[3], pd[3], rd[3], hl[3];
@@ -858,6 +859,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       Dcol[j] = ct ? -pick3(sb, Jl[j], Jl[3 + j], Jl[6 + j]) : pick3(sb, Pm[3 * j], Pm[3 * j + 1], Pm[3 * j + 2]);
     }
   }
+  WBC_STAMP(11);
   WBC_HCUT_AT(2, X[0] + X[7] + X[17] + Y[3] + Y[16] + hbN[0] + hbN[5] + lm + lh[1] + lI[3] + Cb_leg[2] + Cl[1] + xi[0] + t0_own + Yrow[2] + Drow[1] + Ji[4] + Mll6[2] + jdxi[0] + xt_s[0] + xdt_s[1] + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1])
   // ---------------- base: bias wrench, composite inertia -> Gs = G_b, kv
   double Gs[6][6], kv[6];
@@ -921,6 +923,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       ab0[i] = qo.leg_bcast(bcol[i], 3);
     }
   }
+  WBC_STAMP(12);
   WBC_HCUT_AT(3, bcol[0] + bcol[5] + ab0[2] + Cb_leg[2] + Cl[1] + xi[0] + t0_own + Yrow[2] + Drow[1] + Y[4] + Ji[4] + Mll6[2] + jdxi[0] + xt_s[0] + xdt_s[1] + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1] + kv[0])
   // ---------------- level-1 rows
   const double eps = sqrt(P.eps2);
@@ -1138,6 +1141,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     }
     init_rcol();
   }
+  WBC_STAMP(13);
   WBC_HCUT_AT(4, Acol[0] + Acol[5] + Acol[P1 - 1] + Rcol[0] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   level2_rows(Acol + P1);
   // ---------------- what the friction phase itself needs of the end-of-tick data (torque box, PC row) ...
@@ -1184,6 +1188,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   }
 #endif
   hex_qr_append<Q, P1 + NZ, NV>(qo, Rcol, Acol);
+  WBC_STAMP(14);
   WBC_HCUT_AT(5, Rcol[0] + Rcol[5] + Rcol[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- own row of J = R^-1 and unconstrained minimiser
   double z, Jr[NV];
@@ -1230,6 +1235,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     });
     z = zacc;
   }
+  WBC_STAMP(15);
   WBC_HCUT_AT(6, z + Jr[0] + Jr[5] + Jr[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- friction rows (+ the optional torque box)
   int iters = 0;
@@ -1250,6 +1256,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     if (st != ST_OK) status = st;
   }
   *iters_out = iters;
+  WBC_STAMP(6);
   WBC_HCUT_AT(7, z + (double)iters + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- outputs: a_b = ab0 + sum B z ;  tau_(l,j) = Y_l[j] a_b + D_l[j] z_l + t0_l[j]
   double jic[3];

@@ -20,6 +20,11 @@ t = buf[:, :6].astype(np.int64)
 d = np.diff(t, axis=1)
 names = ["kernarg + address setup + load issue", "mask/mu loads issued -> loads landed, LDS writes", "barrier", "tick", "stats tail"]
 for i, nm in enumerate(names): print("%-52s median %7d  p90 %7d cycles" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 90)))
+# phase stamps inside the tick: 3 (start) -> 10 state -> 11 leg -> 12 G_b + solve -> 13 level-1 rows -> 14 append -> 15 J rows -> 6 active set -> 4 outputs
+ph = buf[:, [3, 10, 11, 12, 13, 14, 15, 6, 4]].astype(np.int64)
+dp = np.diff(ph, axis=1)
+for i, nm in enumerate(["state", "leg", "G_b + solve", "level-1 rows (+ level-2 rows, park)", "30-row append", "J rows, z", "active set", "outputs"]):
+    print("  phase %-38s median %6d  p90 %6d  max %6d cycles" % (nm, np.median(dp[:, i]), np.percentile(dp[:, i], 90), dp[:, i].max()))
 tot = t[:, 5] - t[:, 0]
 print("wave lifetime first->last stamp: p10 %d p50 %d p90 %d p99 %d max %d cycles" % tuple(np.percentile(tot, [10, 50, 90, 99, 100])))
 print("first stamp spread across blocks (launch skew): p10 %d p50 %d p90 %d max %d cycles" % tuple(np.percentile(t[:, 0] - t[:, 0].min(), [10, 50, 90, 100])))
