@@ -165,3 +165,22 @@ def test_pc_enforces_passivity_where_mptc_does_not():
     tau_p, met_p, st_p, _ = ht.run("pc", t["flat"], b["q"], b["v"], b["targets"], b["mask"])
     assert (met_m[3] > 1e-6).sum() >= 3            # the batch does contain Vdot > 0 cases
     assert (st_p == 0).all() and met_p[3].max() < 1e-9
+
+
+def test_fast_and_generic_paths_round_identically():
+    """A robot's result may not depend on its wave-mates: leaving the active set's compile-time-q fast path at any trip
+    (what a wave-mate's drop causes) must give the same bits.  Host instantiation; the device A/B is tools/dump_tau.py
+    on -DWBC_DEV_FORCE_BAIL=k builds (bit-identical)."""
+    L = ht.lib()
+    for cfg, kind in ((2, "id"), (3, "mptc"), (3, "id")):
+        b = workloads.make_batch(cfg, n=32)
+        t = orc.load_model_json(b["model"])
+        L.host_gi_force_bail(-1)
+        ref = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], hexv=True)
+        try:
+            for k in range(8):
+                L.host_gi_force_bail(k)
+                r = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], hexv=True)
+                assert np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1]) and np.array_equal(r[3], ref[3]), (kind, k)
+        finally:
+            L.host_gi_force_bail(-1)
