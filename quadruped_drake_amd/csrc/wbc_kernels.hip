@@ -227,6 +227,25 @@ struct ParkLds {
   __device__ __forceinline__ double lget(int i) const { return la[z + i * HEX_BLOCK]; }
 };
 
+// XCD-aware workgroup -> robots mapping.  A 64-thread workgroup stages 4 robots = one 32-byte segment of every input row, and the
+// hardware deals workgroups round-robin over the 8 XCDs (each with its own L2), so with the identity mapping the four segments of
+// a 128-byte line are fetched by four different XCDs: FETCH_SIZE measured 4x the algorithmic input bytes (calibrated on the same
+// access shape: tools/micro/fetch_calib.hip, profiles/r02/fetch_calib.md).  Here workgroups b, b+8, b+16, b+24 -- the same XCD --
+// take the four segments of one line.  Placement is only a speed / traffic matter; any mapping is correct.
+#ifndef WBC_XCD_REMAP
+#define WBC_XCD_REMAP 1
+#endif
+__device__ __forceinline__ int hex_effective_block(int b, int nblocks) {
+#if WBC_XCD_REMAP
+  const int full = nblocks & ~31;                 // groups of 32 workgroups = 8 XCDs x 4 segments; the ragged tail keeps the identity
+  if (b >= full) return b;
+  const int g = b >> 5, x = b & 7, y = (b >> 3) & 3;
+  return (g << 5) + (x << 2) + y;
+#else
+  return b;
+#endif
+}
+
 #ifndef WBC_HEX_WAVES_PER_EU
 #define WBC_HEX_WAVES_PER_EU 1
 #endif
@@ -254,7 +273,8 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   }
 #endif
   const int slot = threadIdx.x >> 4;
-  const int i = blockIdx.x * HROBOTS + slot;
+  const int eb = hex_effective_block(blockIdx.x, gridDim.x);
+  const int i = eb * HROBOTS + slot;
   const bool live = i < n;
   const int ii = live ? i : (n - 1);
   // Prologue: EVERY global load of the tick is issued here, unconditionally (clamped indices, no divergent
@@ -265,7 +285,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
 #pragma unroll
   for (int j = 0; j < MPER; j++) t[j] = msrc[min(j * HEX_BLOCK + (int)threadIdx.x, MODEL_PAD_WORDS - 1)];
   {
-    const int r0 = blockIdx.x * HROBOTS;
+    const int r0 = eb * HROBOTS;
 #pragma unroll
     for (int j = 0; j < PER_LANE; j++) {
       const int idx = min(j * HEX_BLOCK + (int)threadIdx.x, NIN * HROBOTS - 1);
@@ -361,7 +381,7 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* _
   __shared__ double outbuf[HROBOTS * 18];
   __shared__ double robuf[HROBOTS * 4];     // per robot: time, lookup hint, mu, mass scale (loop-carried, kept out of registers)   // last tick: tau (12), metrics (4), status, mask -- written to HBM once, after the loop
   const int slot = threadIdx.x >> 4;
-  const int i = blockIdx.x * HROBOTS + slot;
+  const int i = hex_effective_block(blockIdx.x, gridDim.x) * HROBOTS + slot;
   const bool live = i < n;
   const int ii = live ? i : (n - 1);
   HexDev qo;
