@@ -241,6 +241,8 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         key = qo.min16(key);
         pf = (key < 1e299) ? hex_key_index(key) : -1;
       }
+      // every wavefront's last trip finds nothing left to repair anywhere: leave before the crossbar round trip
+      if (qo.wave_all(done || pf < 0)) { done = true; stop = true; generic = false; return; }
       // ONE round trip: the picked row's image, value and norm from its lane (own lane when there is no candidate)
       const int pl = (pf >= 0) ? pf : h;
       double d[NZ];
