@@ -57,6 +57,19 @@ constexpr int BLOCK = 64;
 constexpr int STAT_SLOTS = 2048;
 static_assert(sizeof(StatsDev) == 22 * 8, "StatsDev is 22 eight-byte words (wbc_stats_reduce_kernel)");
 
+// The slots are stored WORD-major (word w of slot s at words[w * STAT_SLOTS + s]): the reduction reads each word's 2048
+// slots as one coalesced stream (the slot-major layout cost 11 us per wbc_stats_get, profiles/r02/hex_kernel_stats.csv).
+__device__ __forceinline__ void stat_add(StatsDev* stats, unsigned block, int st, int iters, double tau_sum, double tau_max, double err, unsigned mk) {
+  double* w = reinterpret_cast<double*>(stats) + (block & (STAT_SLOTS - 1));
+  atomicAdd(w + 0 * STAT_SLOTS, 1.0);
+  if (st != 0) atomicAdd(w + 1 * STAT_SLOTS, 1.0);
+  atomicAdd(w + 2 * STAT_SLOTS, (double)iters);
+  atomicAdd(w + 3 * STAT_SLOTS, tau_sum);
+  atomicMax(reinterpret_cast<unsigned long long*>(w + 4 * STAT_SLOTS), (unsigned long long)__double_as_longlong(tau_max));
+  atomicAdd(w + 5 * STAT_SLOTS, err);
+  atomicAdd(w + (6 + mk) * STAT_SLOTS, 1.0);
+}
+
 __device__ __forceinline__ double wave_sum(double x) {
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
   return x;
@@ -343,14 +356,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
     // the block's slot (no wave-wide shuffles, no waits at the tail of the kernel)
     const double ts = qo.sum16(tsum), tm = qo.max16(tmax);
     if (live && lead) {
-      stats += blockIdx.x & (STAT_SLOTS - 1);
-      atomicAdd(&stats->ticks, 1.0);
-      if (st != 0) atomicAdd(&stats->status_nonzero, 1.0);
-      atomicAdd(&stats->iters_sum, (double)iters);
-      atomicAdd(&stats->tau_abs_sum, ts);
-      atomicMax(&stats->tau_abs_max_bits, (unsigned long long)__double_as_longlong(tm));
-      atomicAdd(&stats->err_sum, errv);
-      atomicAdd(&stats->mask_count[mk], 1.0);
+      stat_add(stats, blockIdx.x, st, iters, ts, tm, errv, mk);
     }
   }
   WBC_STAMP(5);
@@ -451,14 +457,7 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* _
     if (stats) {
       const double ts = qo.sum16(tsum), tm = qo.max16(tmax);
       if (live && lead) {
-        StatsDev* sd = stats + (blockIdx.x & (STAT_SLOTS - 1));
-        atomicAdd(&sd->ticks, 1.0);
-        if (st != 0) atomicAdd(&sd->status_nonzero, 1.0);
-        atomicAdd(&sd->iters_sum, (double)iters);
-        atomicAdd(&sd->tau_abs_sum, ts);
-        atomicMax(&sd->tau_abs_max_bits, (unsigned long long)__double_as_longlong(tm));
-        atomicAdd(&sd->err_sum, errv);
-        atomicAdd(&sd->mask_count[mk], 1.0);
+        stat_add(stats, blockIdx.x, st, iters, ts, tm, errv, mk);
       }
     }
     __syncthreads();
@@ -543,16 +542,23 @@ __global__ void wbc_integrate_kernel(int n, int ld, double dt, double* __restric
   for (int r = 0; r < 12; r++) q[(size_t)(7 + r) * ld + i] += dt * vn[6 + r];
 }
 
-// out <- sum / max over all slots: one 64-lane block per statistics word
-__global__ void wbc_stats_reduce_kernel(StatsDev* __restrict__ st, StatsDev* __restrict__ out) {
+// out <- sum / max over all slots: one 256-thread block per statistics word, coalesced reads (word-major slots)
+__global__ void __launch_bounds__(256) wbc_stats_reduce_kernel(const StatsDev* __restrict__ st, StatsDev* __restrict__ out) {
+  __shared__ double part[4];
   const int w = blockIdx.x;  // word 4 is the max (bit pattern of a non-negative double)
+  const double* src = reinterpret_cast<const double*>(st) + (size_t)w * STAT_SLOTS;
   double acc = 0.0;
-  for (int sl = threadIdx.x; sl < STAT_SLOTS; sl += 64) {
-    const double x = reinterpret_cast<const double*>(st + sl)[w];
+  for (int sl = threadIdx.x; sl < STAT_SLOTS; sl += 256) {
+    const double x = src[sl];
     acc = (w == 4) ? fmax(acc, x) : acc + x;
   }
   acc = (w == 4) ? wave_max(acc) : wave_sum(acc);
-  if (threadIdx.x == 0) reinterpret_cast<double*>(out)[w] = acc;
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double r = (w == 4) ? fmax(fmax(part[0], part[1]), fmax(part[2], part[3])) : (part[0] + part[1]) + (part[2] + part[3]);
+    reinterpret_cast<double*>(out)[w] = r;
+  }
 }
 
 __global__ void wbc_advance_time_kernel(int n, double dt, double* __restrict__ time) {
@@ -823,11 +829,11 @@ int wbc_time_steps_each(wbc_handle h, int steps, int n, int ld, const double* q,
 int wbc_stats_get(wbc_handle h, wbc_stats* out) {
   if (!h || !out) return misuse("wbc_stats_get: null argument");
   HIP_TRY(hipSetDevice(h->device));
-  HIP_TRY(hipStreamSynchronize(h->stream));
   StatsDev s;
   StatsDev* dst = nullptr;
   HIP_TRY(hipHostGetDevicePointer((void**)&dst, h->h_stats, 0));
-  hipLaunchKernelGGL(wbc_stats_reduce_kernel, dim3(sizeof(StatsDev) / 8), dim3(64), 0, h->stream, h->d_stats, dst);
+  // stream order: the reduction runs after every launch queued so far -- no wait before it
+  hipLaunchKernelGGL(wbc_stats_reduce_kernel, dim3(sizeof(StatsDev) / 8), dim3(256), 0, h->stream, h->d_stats, dst);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));   // the only wait: the totals are already in host memory
   memcpy(&s, h->h_stats, sizeof s);
