@@ -179,6 +179,29 @@ class BatchedController:
         _lib.check(self._L.wbc_time_steps_each(self._h, int(steps), n, n, *ptrs, ms))
         return np.array(ms[:], dtype=np.float64), outs
 
+    def bind(self, q, v, targets, contact_mask, mu=None, mass_scale=None, out=None):
+        """Validate the tensors ONCE and return a callable bundle for repeated ticks on the same buffers (a control loop
+        steps the same device arrays every tick; the per-call checks of step() cost ~10 us of Python each)."""
+        n, keep, ptrs, outs = self._args(q, v, targets, contact_mask, mu, mass_scale, out)
+        ctrl = self
+
+        class Bound:
+            outputs = outs
+            _keep = keep
+
+            def step(self):
+                ctrl._bind_stream()
+                _lib.check(ctrl._L.wbc_step(ctrl._h, n, n, *ptrs))
+                return outs
+
+            def time_steps(self, steps):
+                ms = C.c_float(0)
+                ctrl._bind_stream()
+                _lib.check(ctrl._L.wbc_time_steps(ctrl._h, int(steps), n, n, *ptrs, C.byref(ms)))
+                return ms.value
+
+        return Bound()
+
     def sync(self):
         _lib.check(self._L.wbc_sync(self._h))
 

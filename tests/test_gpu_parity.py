@@ -112,6 +112,26 @@ def test_empty_batch_and_misuse():
     ctrl.close()
 
 
+def test_bound_buffers_tick_like_step():
+    """bind() validates once; its step()/time_steps() are the same C-ABI calls on the same buffers."""
+    torch = _torch()
+    from quadruped_drake_amd import MPTCController, workloads
+    b = workloads.make_batch(3, n=256)
+    up = lambda x: torch.tensor(np.ascontiguousarray(x), device="cuda:0")
+    ctrl = MPTCController(model=b["model"], max_batch=256, device=0)
+    q, v, tg, mask = up(b["q"]), up(b["v"]), up(b["targets"]), up(b["mask"])
+    tau, met, st = (x.clone() for x in ctrl.step(q, v, tg, mask)); ctrl.sync()
+    bound = ctrl.bind(q, v, tg, mask)
+    tau2, met2, st2 = bound.step(); ctrl.sync()
+    assert torch.equal(tau, tau2) and torch.equal(met, met2) and torch.equal(st, st2)
+    tau2.zero_()
+    assert bound.time_steps(3) > 0.0
+    assert torch.equal(tau, bound.outputs[0])
+    with pytest.raises(ValueError):
+        ctrl.bind(q.float(), v, tg, mask)
+    ctrl.close()
+
+
 def test_torque_box_friction_and_host_pointer_mode():
     from oracle import oracle_py as orc
     from quadruped_drake_amd import IDController, workloads
