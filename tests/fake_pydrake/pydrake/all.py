@@ -117,6 +117,60 @@ class LeafSystem:
         return context.inputs[i]
 
 
+class _AbstractOutputPort:
+    def __init__(self, system, index, name, alloc, calc):
+        self.system, self.index, self.name, self.alloc, self.calc = system, index, name, alloc, calc
+
+    def Eval(self, context):
+        out = self.alloc()
+        self.calc(context, out)
+        return out.get_value()
+
+
+def _declare_abstract_output_port(self, name, alloc, calc):
+    p = _AbstractOutputPort(self, len(self._out), name, alloc, calc)
+    self._out.append(p)
+    return p
+
+
+LeafSystem.DeclareAbstractOutputPort = _declare_abstract_output_port
+AbstractValue.get_mutable_value = AbstractValue.get_value
+
+
+# geometry names the trunk planners touch for the visualiser output (planners/simple.py:24-33,126-139): containers only
+class RigidTransform:
+    def __init__(self):
+        self.rotation, self.translation = None, np.zeros(3)
+
+    def set_rotation(self, r):
+        self.rotation = r
+
+    def set_translation(self, p):
+        self.translation = np.asarray(p, dtype=float).copy()
+
+
+class RollPitchYaw:
+    def __init__(self, rpy):
+        self.rpy = np.asarray(rpy, dtype=float).copy()
+
+    def vector(self):
+        return self.rpy
+
+
+class FramePoseVector:
+    def __init__(self):
+        self._d = {}
+
+    def set_value(self, frame_id, X):
+        self._d[frame_id] = X
+
+    def value(self, frame_id):
+        return self._d[frame_id]
+
+    def clear(self):
+        self._d.clear()
+
+
 class _Joint:
     def __init__(self, vstart):
         self._vs = vstart
