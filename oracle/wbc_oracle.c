@@ -3,7 +3,7 @@
  *
  * Every function cites the reference file:line it restates.  The rigid-body terms restate
  * what the Drake calls at those lines are documented to return (Drake itself is absent:
- * "parity unpinned", see header).  Deliberately dense and literal: M is built from 18
+ * "parity unpinned" at that boundary, see header).  Deliberately dense and literal: M is built from 18
  * inverse-dynamics passes like CalcMassMatrixViaInverseDynamics, the QP is assembled in
  * the reference's 30+3nc variables, matrices are inverted where the reference inverts.
  */

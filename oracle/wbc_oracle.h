@@ -9,11 +9,18 @@
  *   helpers.py:5-33
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may call it.
  *
- * PARITY UNPINNED: the reference's arithmetic lives in Drake MultibodyPlant and OSQP
- * (both un-vendored, unpinned, absent here) and the reference ships no golden vectors
- * for this path.  This oracle restates Drake's *documented* semantics and is pinned by
- * (1) analytic known answers, (2) an independent energy-based numpy derivation and
- * (3) scipy QP solves -- see tests/ and DESIGN.md.
+ * PARITY UNPINNED AT THE DRAKE / OSQP BOUNDARY: the rigid-body numbers and the QP solve of
+ * the reference live in Drake MultibodyPlant and OSQP (both un-vendored, unpinned, absent
+ * here) and the reference ships no golden vectors for this path.  What IS pinned by the
+ * reference itself: everything its own Python defines above that boundary -- targets,
+ * gains, RPY handling, Lambda / Jbar / Q / f_des, the Coriolis-matrix and Jdot definitions,
+ * QP assembly, logging -- against outputs of the reference's controllers/*.py EXECUTED in
+ * this container over stand-ins for the plant and the solver
+ * (tests/golden/make_reference_law_golden.py, tests/test_reference_law.py: torques within
+ * 9e-7, all four laws, every contact mask, both robots).  Below the boundary this oracle
+ * restates Drake's *documented* semantics and is backed by (1) analytic known answers,
+ * (2) an independent energy-based numpy derivation and (3) scipy QP solves -- see tests/
+ * and DESIGN.md.
  *
  * Conventions (Drake's, as the reference relies on them):
  *   q = [qw qx qy qz | x y z | 12 joints]      (simulate.py:171-176)

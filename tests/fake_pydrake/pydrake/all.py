@@ -140,21 +140,46 @@ AbstractValue.get_mutable_value = AbstractValue.get_value
 # geometry names the trunk planners touch for the visualiser output (planners/simple.py:24-33,126-139): containers only
 class RigidTransform:
     def __init__(self):
-        self.rotation, self.translation = None, np.zeros(3)
+        self._R, self._p = None, np.zeros(3)
 
     def set_rotation(self, r):
-        self.rotation = r
+        self._R = r
 
     def set_translation(self, p):
-        self.translation = np.asarray(p, dtype=float).copy()
+        self._p = np.asarray(p, dtype=float).copy()
+
+    def rotation(self):
+        return self._R
+
+    def translation(self):
+        return self._p
 
 
 class RollPitchYaw:
-    def __init__(self, rpy):
-        self.rpy = np.asarray(rpy, dtype=float).copy()
+    """Drake's documented convention: R = Rz(yaw) Ry(pitch) Rx(roll); w_parent = E(rpy) rpyDt with
+    E = [[cp cy, -sy, 0], [cp sy, cy, 0], [-sp, 0, 1]]  (written from the documentation, not from Drake sources)."""
+
+    def __init__(self, x):
+        if hasattr(x, "matrix"):
+            R = x.matrix()
+            self.rpy = np.array([np.arctan2(R[2, 1], R[2, 2]), np.arctan2(-R[2, 0], np.hypot(R[0, 0], R[1, 0])),
+                                 np.arctan2(R[1, 0], R[0, 0])])
+        else:
+            self.rpy = np.asarray(x, dtype=float).reshape(3).copy()
 
     def vector(self):
         return self.rpy
+
+    def _E(self):
+        r, p, y = self.rpy
+        cp, sp, cy, sy = np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+        return np.array([[cp * cy, -sy, 0.0], [cp * sy, cy, 0.0], [-sp, 0.0, 1.0]])
+
+    def CalcAngularVelocityInParentFromRpyDt(self, rpyDt):
+        return self._E() @ np.asarray(rpyDt, dtype=float)
+
+    def CalcRpyDtFromAngularVelocityInParent(self, w):
+        return np.linalg.solve(self._E(), np.asarray(w, dtype=float))
 
 
 class FramePoseVector:
@@ -205,3 +230,25 @@ class FakePlant:
         for k, j in enumerate(self._act):
             B[6 + self._order[j], k] = 1.0
         return B
+
+
+# ---- names the reference's controllers pull in through `from pydrake.all import *` (controllers/*.py)
+from .autodiffutils import AutoDiffXd  # noqa: E402
+from .mathprog import MathematicalProgram, OsqpSolver, GurobiSolver  # noqa: E402
+from .refplant import JacobianWrtVariable, RefPlant, RotationMatrix  # noqa: E402
+
+
+def jacobian(function, x):
+    """pydrake.forwarddiff.jacobian as documented: seed x with unit derivatives, evaluate, stack the derivatives."""
+    x = np.asarray(x, dtype=float)
+    x_ad = np.empty(x.shape, dtype=object)
+    for i in range(x.size):
+        d = np.zeros(x.size); d[i] = 1.0
+        x_ad.flat[i] = AutoDiffXd(x.flat[i], d)
+    y_ad = np.asarray(function(x_ad), dtype=object)
+    return np.vstack([y.derivatives() for y in y_ad.flat]).reshape(y_ad.shape + (-1,))
+
+
+def ContinuousAlgebraicRiccatiEquation(A, B, Q, R):
+    import scipy.linalg
+    return scipy.linalg.solve_continuous_are(A, B, Q, R)

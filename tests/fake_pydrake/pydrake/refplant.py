@@ -1,0 +1,177 @@
+"""TEST-ONLY stand-in for the slice of pydrake's MultibodyPlant the reference's controllers call
+(controllers/basic_controller.py:89-269).  The rigid-body quantities come from oracle/ (M, Cv, tau_g, frame positions,
+Jacobians, bias accelerations) in Drake's documented conventions (world-frame base velocities [w; v], CalcBiasTerm without
+gravity, CalcGravityGeneralizedForces = the force side).  The two autodiff recipes of the reference are served as
+derivatives, NOT by handing over the oracle's own C / Jdot:
+  * CalcBiasTerm on velocities seeded with derivatives (basic_controller.py:117-132): dCv/dv by central differences with
+    step 1 -- exact for the quadratic form Cv;
+  * CalcJacobianTranslationalVelocity on positions seeded with derivatives (basic_controller.py:198-220): dJ/dq by
+    Richardson-extrapolated central differences of the oracle's foot Jacobian (error ~1e-11).
+So a run of the reference's ControlLaw over this plant checks the oracle's Coriolis matrix and Jdot against the
+reference's DEFINITIONS of them, and everything downstream against the reference's own arithmetic."""
+import numpy as np
+
+from oracle import oracle_py as orc
+from .autodiffutils import join, split
+
+FEET = {"LF_FOOT": 0, "RF_FOOT": 1, "LH_FOOT": 2, "RH_FOOT": 3}
+
+
+class JacobianWrtVariable:
+    kQDot, kV = 0, 1
+
+
+class Frame:
+    def __init__(self, name):
+        self.name = name
+
+
+class RotationMatrix:
+    def __init__(self, R):
+        self._R = np.array(R, dtype=float)
+
+    def matrix(self):
+        return self._R
+
+
+class SpatialAcceleration:
+    def __init__(self, c):
+        self._c = np.array(c, dtype=float)
+
+    def get_coeffs(self):
+        return self._c
+
+
+class _Pose:
+    def __init__(self, R, p):
+        self._R, self._p = RotationMatrix(R), np.array(p, dtype=float)
+
+    def translation(self):
+        return self._p
+
+    def rotation(self):
+        return self._R
+
+
+class PlantContext:
+    def __init__(self):
+        self.q = np.zeros(19); self.q[0] = 1.0
+        self.v = np.zeros(18)
+        self.qD = self.vD = None        # derivative seeds (autodiff plant only)
+
+
+class RefPlant:
+    """Floating base + 12 joints in the canonical leg-major order; actuator k drives joint k."""
+
+    def __init__(self, model_name="mini_cheetah", body_frame="body", autodiff=False):
+        self.model_name, self.body_frame_name, self.autodiff = model_name, body_frame, autodiff
+        self.m = orc.model(model_name)
+
+    # -- bookkeeping
+    def CreateDefaultContext(self):
+        return PlantContext()
+
+    def ToAutoDiffXd(self):
+        return RefPlant(self.model_name, self.body_frame_name, autodiff=True)
+
+    def num_positions(self):
+        return 19
+
+    def num_velocities(self):
+        return 18
+
+    def num_actuators(self):
+        return 12
+
+    def world_frame(self):
+        return Frame("world")
+
+    def GetFrameByName(self, name):
+        if name != self.body_frame_name and name not in FEET:
+            raise RuntimeError("no frame named %r" % name)
+        return Frame(name)
+
+    def SetPositions(self, ctx, q):
+        ctx.q, ctx.qD = split(q)
+
+    def SetVelocities(self, ctx, v):
+        ctx.v, ctx.vD = split(v)
+
+    def GetPositions(self, ctx):
+        return ctx.q.copy()
+
+    def GetVelocities(self, ctx):
+        return ctx.v.copy()
+
+    def MakeActuationMatrix(self):
+        B = np.zeros((18, 12)); B[6:, :] = np.eye(12)
+        return B
+
+    def MapVelocityToQDot(self, ctx, v):
+        """qdot = N(q) v for the quaternion floating base with world-frame angular velocity: quat' = 1/2 (0, w) * quat."""
+        w, x, y, z = ctx.q[:4]
+        om = np.asarray(v[:3], dtype=float)
+        qd = np.zeros(19)
+        qd[0] = -0.5 * (om[0] * x + om[1] * y + om[2] * z)
+        qd[1:4] = 0.5 * (w * om + np.cross(om, [x, y, z]))
+        qd[4:7] = v[3:6]
+        qd[7:] = v[6:]
+        return qd
+
+    # -- dynamics
+    def CalcMassMatrixViaInverseDynamics(self, ctx):
+        return orc.calc_dynamics(self.m, ctx.q, ctx.v)[0]
+
+    def CalcBiasTerm(self, ctx):
+        Cv = orc.calc_dynamics(self.m, ctx.q, ctx.v)[1]
+        if ctx.vD is None:
+            return Cv
+        assert self.autodiff and ctx.qD is None
+        dC = np.zeros((18, 18))
+        for j in range(18):
+            e = np.zeros(18); e[j] = 1.0
+            dC[:, j] = 0.5 * (orc.calc_dynamics(self.m, ctx.q, ctx.v + e)[1] - orc.calc_dynamics(self.m, ctx.q, ctx.v - e)[1])
+        return join(Cv, dC @ ctx.vD)
+
+    def CalcGravityGeneralizedForces(self, ctx):
+        return -orc.calc_dynamics(self.m, ctx.q, ctx.v)[2]          # the reference flips the sign (basic_controller.py:112)
+
+    # -- frames
+    def CalcRelativeTransform(self, ctx, frame_A, frame_B):
+        assert frame_A.name == "world" and frame_B.name == self.body_frame_name
+        R, p, _, _ = orc.body_quantities(self.m, ctx.q, ctx.v)
+        return _Pose(R, p)
+
+    def CalcJacobianSpatialVelocity(self, ctx, wrt, frame, p_BoBp, frame_A, frame_E):
+        assert wrt == JacobianWrtVariable.kV and frame.name == self.body_frame_name and not np.any(p_BoBp)
+        return orc.body_quantities(self.m, ctx.q, ctx.v)[2]
+
+    def CalcBiasSpatialAcceleration(self, ctx, wrt, frame, p_BoBp, frame_A, frame_E):
+        assert wrt == JacobianWrtVariable.kV and frame.name == self.body_frame_name and not np.any(p_BoBp)
+        return SpatialAcceleration(orc.body_quantities(self.m, ctx.q, ctx.v)[3])
+
+    def CalcPointsPositions(self, ctx, frame, p_BQ, frame_A):
+        assert not np.any(p_BQ) and frame_A.name == "world"
+        return orc.foot_quantities(self.m, ctx.q, ctx.v, FEET[frame.name])[0].reshape(3, 1)
+
+    def _J(self, q, v, foot):
+        return orc.foot_quantities(self.m, q, v, foot)[1]
+
+    def CalcJacobianTranslationalVelocity(self, ctx, wrt, frame, p_BoBp, frame_A, frame_E):
+        assert wrt == JacobianWrtVariable.kV and not np.any(p_BoBp)
+        foot = FEET[frame.name]
+        J = self._J(ctx.q, ctx.v, foot)
+        if ctx.qD is None:
+            return J
+        assert self.autodiff
+        dJ = np.zeros((3, 18, 19))
+        for k in range(19):
+            e = np.zeros(19); e[k] = 1.0
+            d = lambda h: (self._J(ctx.q + h * e, ctx.v, foot) - self._J(ctx.q - h * e, ctx.v, foot)) / (2.0 * h)
+            h = 2e-3
+            dJ[:, :, k] = (4.0 * d(0.5 * h) - d(h)) / 3.0          # Richardson: O(h^4)
+        return join(J, dJ @ ctx.qD)
+
+    def CalcBiasTranslationalAcceleration(self, ctx, wrt, frame, p_BoBp, frame_A, frame_E):
+        assert wrt == JacobianWrtVariable.kV and not np.any(p_BoBp)
+        return orc.foot_quantities(self.m, ctx.q, ctx.v, FEET[frame.name])[2].reshape(3, 1)

@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Golden vectors produced by EXECUTING the reference's own controller code
+(/root/reference/controllers/{inverse_dynamics,mptc,pc,clf}_controller.py + basic_controller.py + helpers.py:
+imported from where they lie, never copied) on this repository's seeded inputs.
+
+What runs and what does not.  The controllers are Drake LeafSystems; their ControlLaw is numpy arithmetic around three
+services of pydrake, none of which is in this image: a MultibodyPlant (rigid-body terms), MathematicalProgram (a
+container for numeric costs / constraints) and OsqpSolver.  tests/fake_pydrake supplies stand-ins:
+  * refplant.RefPlant      rigid-body terms from oracle/ in Drake's documented conventions; the reference's two autodiff
+                           recipes (Coriolis matrix = 1/2 d(Cv)/dv, Jdot = dJ/dq N(q) v) are served as derivatives of
+                           the oracle's Cv and J, not with the oracle's own C / Jdot;
+  * mathprog               records the QP exactly as the reference's Add* builders state it, then solves it exactly
+                           (extended-precision KKT active set, independent of oracle/ and of the kernels) under this
+                           repository's tie-break (+ 1/2 eps2 |[tau; f (; delta)]|^2) -- NOT OSQP.
+So these fixtures pin, against the reference's executed code: target / gain arithmetic, RPY handling, the task-space
+terms (Lambda, Jbar, Q, f_des), the Coriolis-matrix and Jdot definitions, QP assembly (cost forms, signs, rows,
+variable order) and the logged metrics.  They do NOT pin Drake's rigid-body numbers (supplied by oracle/; checked
+separately against tests/energy_model.py) or OSQP's selection among the optimal set: parity at the Drake / OSQP
+boundary stays unpinned.
+
+Output: reference_law_golden.npz -- per case set `<set>_*`: inputs (q, v, targets, mask[, mu, mass_scale]) and what the
+reference's code returned: tau[12], metrics [V, err, res, Vdot] (res = the stand-in solver's equality residual), the
+QP solution's vd[18] and contact forces f[12] (LF RF LH RH, zero for swing feet), active-set size.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.join(HERE, "..", "..")
+sys.path.insert(0, os.path.join(HERE, "..", "fake_pydrake"))
+sys.path.insert(0, ROOT)
+sys.modules["lcm"] = types.ModuleType("lcm")      # import-only stub: use_lcm=False everywhere below
+np.object = object                                # helpers.py:19 uses the alias numpy removed in 1.24
+sys.path.insert(0, "/root/reference")
+import pydrake.all as fake                         # noqa: E402
+from pydrake.mathprog import OsqpSolver            # noqa: E402
+from controllers import IDController, MPTCController, PCController, CLFController   # noqa: E402  (reference code)
+from oracle import oracle_py as orc                # noqa: E402  (rigid-body terms of the stand-in plant)
+
+LAWS = {"id": IDController, "mptc": MPTCController, "pc": PCController, "clf": CLFController}
+FEET = ("lf", "rf", "lh", "rh")
+BODY = ("p_body", "pd_body", "pdd_body", "rpy_body", "rpyd_body", "rpydd_body")
+
+
+def trunk_dict(t54, mask):
+    """include/wbc.h target rows -> the planner dictionary of planners/simple.py:45-85"""
+    d = {k: t54[3 * i:3 * i + 3].copy() for i, k in enumerate(BODY)}
+    for i, f in enumerate(FEET):
+        for j, pre in enumerate(("p_", "pd_", "pdd_")):
+            d[pre + f] = t54[18 + 9 * i + 3 * j:21 + 9 * i + 3 * j].copy()
+    d["contact_states"] = [bool((int(mask) >> i) & 1) for i in range(4)]
+    d["f_cj"] = np.zeros((3, 4)); d["u2_max"] = 0.0
+    return d
+
+
+def run_set(kind, model, q, v, tg, mask, mu=None, mass_scale=None):
+    plant = fake.RefPlant(model, body_frame="body")      # the reference hard-codes "body" (basic_controller.py:65)
+    ctrl = LAWS[kind](plant, 5e-3)
+    n = q.shape[1]
+    out = dict(tau=np.zeros((12, n)), metrics=np.zeros((4, n)), vd=np.zeros((18, n)), f=np.zeros((12, n)),
+               nactive=np.zeros(n, np.int32))
+    for i in range(n):
+        if mu is not None:
+            ctrl.mu = float(mu[i])                        # the reference's friction coefficient is this attribute
+        if mass_scale is not None:
+            plant.m = orc.model_scaled(model, float(mass_scale[i])); ctrl.plant_autodiff.m = plant.m
+        ctx = ctrl.CreateDefaultContext()
+        ctrl.get_input_port(0).FixValue(ctx, np.concatenate([q[:, i], v[:, i]]))
+        ctrl.get_input_port(1).FixValue(ctx, trunk_dict(tg[:, i], mask[i]))
+        ctrl.V = ctrl.err = ctrl.res = ctrl.Vdot = 0
+        out["tau"][:, i] = ctrl.get_output_port(0).Eval(ctx)            # DoSetControlTorques -> ControlLaw
+        out["metrics"][:, i] = ctrl.get_output_port(1).Eval(ctx)        # SetLoggingOutputs
+        last = OsqpSolver.last
+        x = last["x"]
+        out["vd"][:, i] = x[:18]
+        ct = [k for k in range(4) if (int(mask[i]) >> k) & 1]
+        for j, k in enumerate(ct):
+            out["f"][3 * k:3 * k + 3, i] = x[30 + 3 * j:33 + 3 * j]
+        out["nactive"][i] = len(last["active"])
+    return out
+
+
+gold = {}
+SETS = [("cfg2_id", "id", 16), ("cfg3_id", "id", 16), ("cfg3_mptc", "mptc", 16), ("cfg4_anymal_mptc", "mptc", 8),
+        ("cfg5_rand_mptc", "mptc", 8), ("cfg3_pc", "pc", 16), ("cfg2_pc", "pc", 8), ("cfg3_clf", "clf", 16),
+        ("cfg2_clf", "clf", 8), ("masks16_id", "id", 16), ("masks16_mptc", "mptc", 16), ("masks16_pc", "pc", 16),
+        ("masks16_clf", "clf", 16)]
+for name, kind, n in SETS:
+    z = np.load(os.path.join(HERE, name + ".npz"))
+    sel = np.arange(n)
+    if name.startswith("masks16") and kind in ("mptc", "pc"):
+        sel = sel[z["mask"][:n] != 0]      # the reference's MPTC / PC cannot run in flight (np.vstack of no rows, mptc_controller.py:303)
+    q, v, tg, mk = z["q"][:, sel], z["v"][:, sel], z["targets"][:, sel], z["mask"][sel]
+    mu = z["mu"][sel] if z["mu"].size else None
+    ms = z["mass_scale"][sel] if z["mass_scale"].size else None
+    r = run_set(kind, str(z["model"]), q, v, tg, mk, mu, ms)
+    gold[name + "_kind"] = kind; gold[name + "_model"] = str(z["model"])
+    gold[name + "_q"], gold[name + "_v"], gold[name + "_targets"], gold[name + "_mask"] = q, v, tg, mk
+    gold[name + "_mu"] = np.zeros(0) if mu is None else mu
+    gold[name + "_mass_scale"] = np.zeros(0) if ms is None else ms
+    for k, a in r.items():
+        gold[name + "_" + k] = a
+    # how the oracle's own outputs for the same inputs (already committed in <name>.npz) compare
+    e = np.abs(r["tau"] - z["tau"][:, sel]).max(0) / np.maximum(np.abs(z["tau"][:, sel]).max(0), 1e-3)
+    print("%-18s %-4s n=%2d  tau vs oracle: max rel %.2e  median %.2e   active rows %s" %
+          (name, kind, len(sel), e.max(), np.median(e), np.bincount(r["nactive"]).tolist()))
+np.savez_compressed(os.path.join(HERE, "reference_law_golden.npz"), **gold)
+print("wrote reference_law_golden.npz")
