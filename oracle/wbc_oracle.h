@@ -14,7 +14,7 @@
  * here) and the reference ships no golden vectors for this path.  What IS pinned by the
  * reference itself: everything its own Python defines above that boundary -- targets,
  * gains, RPY handling, Lambda / Jbar / Q / f_des, the Coriolis-matrix and Jdot definitions,
- * QP assembly, logging -- against outputs of the reference's controllers/*.py EXECUTED in
+ * QP assembly, logging -- against outputs of the reference's controller modules EXECUTED in
  * this container over stand-ins for the plant and the solver
  * (tests/golden/make_reference_law_golden.py, tests/test_reference_law.py: torques within
  * 9e-7, all four laws, every contact mask, both robots).  Below the boundary this oracle
