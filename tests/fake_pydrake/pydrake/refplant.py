@@ -61,18 +61,33 @@ class PlantContext:
 
 
 class RefPlant:
-    """Floating base + 12 joints in the canonical leg-major order; actuator k drives joint k."""
+    """Floating base + 12 joints.  Canonical joint j (leg-major) sits at position 7 + order[j] / velocity 6 + order[j]
+    of the plant's own numbering and actuator k drives canonical joint act_joint[k] (defaults: identity) -- the freedom
+    Drake has and the reference comments on (basic_controller.py:310-313).  The oracle is always asked in canonical
+    order; every answer is re-indexed to the plant's numbering."""
 
-    def __init__(self, model_name="mini_cheetah", body_frame="body", autodiff=False):
+    def __init__(self, model_name="mini_cheetah", body_frame="body", autodiff=False, order=None, act_joint=None):
         self.model_name, self.body_frame_name, self.autodiff = model_name, body_frame, autodiff
+        self.order = list(range(12)) if order is None else [int(x) for x in order]
+        self.act_joint = list(range(12)) if act_joint is None else [int(x) for x in act_joint]
+        self.pv = np.array(list(range(6)) + [6 + o for o in self.order])      # canonical i  <->  plant pv[i]
+        self.pq = np.array(list(range(7)) + [7 + o for o in self.order])
         self.m = orc.model(model_name)
+
+    def _vec(self, x_c):                 # canonical 18-vector -> plant numbering
+        out = np.empty_like(x_c); out[self.pv] = x_c
+        return out
+
+    def _cols(self, J_c):                # canonical [.., 18] -> plant numbering on the last-but-derivative axis 1
+        out = np.empty_like(J_c); out[:, self.pv] = J_c
+        return out
 
     # -- bookkeeping
     def CreateDefaultContext(self):
         return PlantContext()
 
     def ToAutoDiffXd(self):
-        return RefPlant(self.model_name, self.body_frame_name, autodiff=True)
+        return RefPlant(self.model_name, self.body_frame_name, autodiff=True, order=self.order, act_joint=self.act_joint)
 
     def num_positions(self):
         return 19
@@ -91,50 +106,57 @@ class RefPlant:
             raise RuntimeError("no frame named %r" % name)
         return Frame(name)
 
-    def SetPositions(self, ctx, q):
-        ctx.q, ctx.qD = split(q)
+    def SetPositions(self, ctx, q):      # the context keeps CANONICAL order
+        val, D = split(q)
+        ctx.q, ctx.qD = val[self.pq], (None if D is None else D[self.pq])
 
     def SetVelocities(self, ctx, v):
-        ctx.v, ctx.vD = split(v)
+        val, D = split(v)
+        ctx.v, ctx.vD = val[self.pv], (None if D is None else D[self.pv])
 
     def GetPositions(self, ctx):
-        return ctx.q.copy()
+        out = np.empty(19); out[self.pq] = ctx.q
+        return out
 
     def GetVelocities(self, ctx):
-        return ctx.v.copy()
+        return self._vec(ctx.v)
 
     def MakeActuationMatrix(self):
-        B = np.zeros((18, 12)); B[6:, :] = np.eye(12)
+        B = np.zeros((18, 12))
+        for k, j in enumerate(self.act_joint):
+            B[6 + self.order[j], k] = 1.0
         return B
 
     def MapVelocityToQDot(self, ctx, v):
         """qdot = N(q) v for the quaternion floating base with world-frame angular velocity: quat' = 1/2 (0, w) * quat."""
         w, x, y, z = ctx.q[:4]
-        om = np.asarray(v[:3], dtype=float)
+        v = np.asarray(v, dtype=float)
+        om = v[:3]
         qd = np.zeros(19)
         qd[0] = -0.5 * (om[0] * x + om[1] * y + om[2] * z)
         qd[1:4] = 0.5 * (w * om + np.cross(om, [x, y, z]))
         qd[4:7] = v[3:6]
-        qd[7:] = v[6:]
+        qd[7:] = v[6:]          # joint rates keep their own (plant) numbering: position 7 + k <-> velocity 6 + k
         return qd
 
     # -- dynamics
     def CalcMassMatrixViaInverseDynamics(self, ctx):
-        return orc.calc_dynamics(self.m, ctx.q, ctx.v)[0]
+        M = np.empty((18, 18)); M[np.ix_(self.pv, self.pv)] = orc.calc_dynamics(self.m, ctx.q, ctx.v)[0]
+        return M
 
     def CalcBiasTerm(self, ctx):
         Cv = orc.calc_dynamics(self.m, ctx.q, ctx.v)[1]
         if ctx.vD is None:
-            return Cv
+            return self._vec(Cv)
         assert self.autodiff and ctx.qD is None
         dC = np.zeros((18, 18))
         for j in range(18):
             e = np.zeros(18); e[j] = 1.0
             dC[:, j] = 0.5 * (orc.calc_dynamics(self.m, ctx.q, ctx.v + e)[1] - orc.calc_dynamics(self.m, ctx.q, ctx.v - e)[1])
-        return join(Cv, dC @ ctx.vD)
+        return join(self._vec(Cv), self._vec(dC @ ctx.vD))
 
     def CalcGravityGeneralizedForces(self, ctx):
-        return -orc.calc_dynamics(self.m, ctx.q, ctx.v)[2]          # the reference flips the sign (basic_controller.py:112)
+        return -self._vec(orc.calc_dynamics(self.m, ctx.q, ctx.v)[2])   # the reference flips the sign (basic_controller.py:112)
 
     # -- frames
     def CalcRelativeTransform(self, ctx, frame_A, frame_B):
@@ -144,7 +166,7 @@ class RefPlant:
 
     def CalcJacobianSpatialVelocity(self, ctx, wrt, frame, p_BoBp, frame_A, frame_E):
         assert wrt == JacobianWrtVariable.kV and frame.name == self.body_frame_name and not np.any(p_BoBp)
-        return orc.body_quantities(self.m, ctx.q, ctx.v)[2]
+        return self._cols(orc.body_quantities(self.m, ctx.q, ctx.v)[2])
 
     def CalcBiasSpatialAcceleration(self, ctx, wrt, frame, p_BoBp, frame_A, frame_E):
         assert wrt == JacobianWrtVariable.kV and frame.name == self.body_frame_name and not np.any(p_BoBp)
@@ -162,7 +184,7 @@ class RefPlant:
         foot = FEET[frame.name]
         J = self._J(ctx.q, ctx.v, foot)
         if ctx.qD is None:
-            return J
+            return self._cols(J)
         assert self.autodiff
         dJ = np.zeros((3, 18, 19))
         for k in range(19):
@@ -170,7 +192,7 @@ class RefPlant:
             d = lambda h: (self._J(ctx.q + h * e, ctx.v, foot) - self._J(ctx.q - h * e, ctx.v, foot)) / (2.0 * h)
             h = 2e-3
             dJ[:, :, k] = (4.0 * d(0.5 * h) - d(h)) / 3.0          # Richardson: O(h^4)
-        return join(J, dJ @ ctx.qD)
+        return join(self._cols(J), self._cols(dJ @ ctx.qD))
 
     def CalcBiasTranslationalAcceleration(self, ctx, wrt, frame, p_BoBp, frame_A, frame_E):
         assert wrt == JacobianWrtVariable.kV and not np.any(p_BoBp)

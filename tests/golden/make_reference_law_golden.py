@@ -56,8 +56,14 @@ def trunk_dict(t54, mask):
     return d
 
 
-def run_set(kind, model, q, v, tg, mask, mu=None, mass_scale=None):
-    plant = fake.RefPlant(model, body_frame="body")      # the reference hard-codes "body" (basic_controller.py:65)
+def run_set(kind, model, q, v, tg, mask, mu=None, mass_scale=None, order=None, act_joint=None):
+    """q, v in CANONICAL joint order; `order` / `act_joint`: the plant's own numbering (refplant.RefPlant)."""
+    plant = fake.RefPlant(model, body_frame="body", order=order, act_joint=act_joint)   # "body": basic_controller.py:65
+    if order is not None:
+        qd, vd_ = q.copy(), v.copy()
+        for j in range(12):
+            qd[7 + order[j]] = q[7 + j]; vd_[6 + order[j]] = v[6 + j]
+        q, v = qd, vd_
     ctrl = LAWS[kind](plant, 5e-3)
     n = q.shape[1]
     out = dict(tau=np.zeros((12, n)), metrics=np.zeros((4, n)), vd=np.zeros((18, n)), f=np.zeros((12, n)),
@@ -75,7 +81,7 @@ def run_set(kind, model, q, v, tg, mask, mu=None, mass_scale=None):
         out["metrics"][:, i] = ctrl.get_output_port(1).Eval(ctx)        # SetLoggingOutputs
         last = OsqpSolver.last
         x = last["x"]
-        out["vd"][:, i] = x[:18]
+        out["vd"][:, i] = x[:18][plant.pv]            # back to canonical order
         ct = [k for k in range(4) if (int(mask[i]) >> k) & 1]
         for j, k in enumerate(ct):
             out["f"][3 * k:3 * k + 3, i] = x[30 + 3 * j:33 + 3 * j]
@@ -107,5 +113,22 @@ for name, kind, n in SETS:
     e = np.abs(r["tau"] - z["tau"][:, sel]).max(0) / np.maximum(np.abs(z["tau"][:, sel]).max(0), 1e-3)
     print("%-18s %-4s n=%2d  tau vs oracle: max rel %.2e  median %.2e   active rows %s" %
           (name, kind, len(sel), e.max(), np.median(e), np.bincount(r["nactive"]).tolist()))
+# the plant numbers its joints breadth-first (all abduction joints first) and its actuators at random: what
+# basic_controller.py:310-313 warns about.  tau comes back in ACTUATOR order; inputs are stored in canonical order.
+ORDER = [4 * (j % 3) + j // 3 for j in range(12)]
+ACT = [int(x) for x in np.random.default_rng(2).permutation(12)]
+for name, kind, n in (("cfg2_id", "id", 8), ("cfg3_mptc", "mptc", 8), ("cfg4_anymal_mptc", "mptc", 4)):
+    z = np.load(os.path.join(HERE, name + ".npz"))
+    q, v, tg, mk = z["q"][:, :n], z["v"][:, :n], z["targets"][:, :n], z["mask"][:n]
+    r = run_set(kind, str(z["model"]), q, v, tg, mk, order=ORDER, act_joint=ACT)
+    pn = "perm_" + name
+    gold[pn + "_kind"] = kind; gold[pn + "_model"] = str(z["model"])
+    gold[pn + "_q"], gold[pn + "_v"], gold[pn + "_targets"], gold[pn + "_mask"] = q, v, tg, mk
+    gold[pn + "_mu"] = np.zeros(0); gold[pn + "_mass_scale"] = np.zeros(0)
+    gold[pn + "_order"], gold[pn + "_act_joint"] = np.array(ORDER), np.array(ACT)
+    for k, a in r.items():
+        gold[pn + "_" + k] = a
+    e = np.abs(r["tau"] - z["tau"][:, :n][ACT]).max(0) / np.maximum(np.abs(z["tau"][:, :n]).max(0), 1e-3)
+    print("%-18s %-4s n=%2d  permuted plant, tau vs oracle[act]: max rel %.2e" % (pn, kind, n, e.max()))
 np.savez_compressed(os.path.join(HERE, "reference_law_golden.npz"), **gold)
 print("wrote reference_law_golden.npz")

@@ -103,3 +103,34 @@ def test_leaf_system_raises_like_the_reference_assert(fake_pydrake):
     with pytest.raises(SolverError):
         sys_.get_output_port(0).Eval(ctx)
     sys_.ctrl.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["perm_cfg2_id", "perm_cfg3_mptc", "perm_cfg4_anymal_mptc"])
+def test_leaf_system_reproduces_the_executed_reference_on_a_permuted_plant(fake_pydrake, name):
+    """The same wiring the reference has -- Controller(plant, dt), quad_state / trunk_input in, quad_torques out -- on a
+    plant that numbers its joints breadth-first and its actuators at random, against what the reference's own
+    controller code returned on such a plant (tests/golden/make_reference_law_golden.py, `perm_*` sets)."""
+    from pydrake.all import FakePlant
+    from quadruped_drake_amd.controller import make_leaf_system
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_law_golden.npz"))
+    g = {k[len(name) + 1:]: z[k] for k in z.files if k.startswith(name + "_")}
+    model, kind = str(g["model"]), str(g["kind"])
+    order, act = [int(x) for x in g["order"]], [int(x) for x in g["act_joint"]]
+    t = load_model(model)
+    names = [l["joint"] for leg in t["legs"] for l in leg["links"]]
+    sys_ = make_leaf_system(FakePlant(names, order, act), 5e-3, control_method=kind.upper(), model=model)
+    for i in range(g["q"].shape[1]):
+        qd = g["q"][:, i].copy(); vd = g["v"][:, i].copy()
+        for j in range(12):
+            qd[7 + order[j]] = g["q"][7 + j, i]; vd[6 + order[j]] = g["v"][6 + j, i]
+        ctx = sys_.CreateDefaultContext()
+        sys_.get_input_port(0).FixValue(ctx, np.concatenate([qd, vd]))
+        sys_.get_input_port(1).FixValue(ctx, _trunk_dict(g["targets"][:, i], int(g["mask"][i])))
+        u = sys_.get_output_port(0).Eval(ctx)
+        met = sys_.get_output_port(1).Eval(ctx)
+        ref = g["tau"][:, i]
+        assert np.abs(u - ref).max() < 1e-5 * max(np.abs(ref).max(), 1e-3), (name, i)
+        cols = [1] if kind == "id" else [0, 1, 3]
+        assert np.allclose(met[cols], g["metrics"][cols, i], rtol=1e-7, atol=1e-7)
+    sys_.ctrl.close()

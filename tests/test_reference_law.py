@@ -17,6 +17,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 SETS = ["cfg2_id", "cfg3_id", "cfg3_mptc", "cfg4_anymal_mptc", "cfg5_rand_mptc", "cfg3_pc", "cfg2_pc", "cfg3_clf", "cfg2_clf",
         "masks16_id", "masks16_mptc", "masks16_pc", "masks16_clf"]
+PERM_SETS = ["perm_cfg2_id", "perm_cfg3_mptc", "perm_cfg4_anymal_mptc"]   # plant with its own joint / actuator numbering
 TAU_TOL, IND_TOL = 1e-5, 1e-7
 
 
@@ -98,3 +99,41 @@ def test_hip_path_matches_the_executed_reference_code(name):
     assert rel(tau, g["tau"]).max() < TAU_TOL, (name, rel(tau, g["tau"]).max())
     check_metrics(met, g["metrics"], g["kind"])
     assert np.abs(vd - g["vd"]).max() < IND_TOL * (1.0 + np.abs(g["vd"]).max())
+
+
+@pytest.mark.parametrize("name", PERM_SETS)
+def test_permuted_plant_oracle_and_host_math(name):
+    """basic_controller.py:310-313: the plant's joint and actuator numbering are its own.  The reference's code ran on a
+    plant with breadth-first joints and random actuators; its torques are the canonical ones re-ordered by act_joint."""
+    import host_tick as ht
+    from oracle import oracle_py as orc
+    from quadruped_drake_amd import load_model
+    g = load(name)
+    act = [int(x) for x in g["act_joint"]]
+    table = dict(load_model(g["model"])); table["act_perm"] = act
+    tau_o, met_o, st_o = orc.step_batch(g["kind"], orc.model(table), orc.params(g["kind"]), g["q"], g["v"], g["targets"], g["mask"])
+    assert (st_o == 0).all() and rel(tau_o, g["tau"]).max() < TAU_TOL
+    check_metrics(met_o, g["metrics"], g["kind"])
+    order = np.array([int(x) for x in g["order"]])
+    q2 = g["q"].copy(); v2 = g["v"].copy()
+    q2[7 + order] = g["q"][7:]; v2[6 + order] = g["v"][6:]
+    tau, met, st, it = ht.run(g["kind"], np.array(table["flat"]), q2, v2, g["targets"], g["mask"], q_perm=order, act_perm=act, hexv=True)
+    assert (st == 0).all() and rel(tau, g["tau"]).max() < TAU_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", PERM_SETS)
+def test_permuted_plant_hip_path(name):
+    import torch
+    from quadruped_drake_amd import IDController, MPTCController
+    g = load(name)
+    order = np.array([int(x) for x in g["order"]]); act = [int(x) for x in g["act_joint"]]
+    q2 = g["q"].copy(); v2 = g["v"].copy()
+    q2[7 + order] = g["q"][7:]; v2[6 + order] = g["v"][6:]
+    n = q2.shape[1]
+    ctrl = {"id": IDController, "mptc": MPTCController}[g["kind"]](model=g["model"], max_batch=n, device=0, q_perm=order, act_perm=act)
+    up = lambda x: torch.tensor(np.ascontiguousarray(x), device="cuda:0")
+    tau, met, st = ctrl.step(up(q2), up(v2), up(g["targets"]), up(g["mask"])); ctrl.sync()
+    tau, st = tau.cpu().numpy(), st.cpu().numpy()
+    ctrl.close()
+    assert (st == 0).all() and rel(tau, g["tau"]).max() < TAU_TOL
