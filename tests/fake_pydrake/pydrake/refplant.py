@@ -66,13 +66,44 @@ class RefPlant:
     Drake has and the reference comments on (basic_controller.py:310-313).  The oracle is always asked in canonical
     order; every answer is re-indexed to the plant's numbering."""
 
-    def __init__(self, model_name="mini_cheetah", body_frame="body", autodiff=False, order=None, act_joint=None):
+    def __init__(self, model_name="mini_cheetah", body_frame="body", autodiff=False, order=None, act_joint=None,
+                 backend="oracle"):
         self.model_name, self.body_frame_name, self.autodiff = model_name, body_frame, autodiff
         self.order = list(range(12)) if order is None else [int(x) for x in order]
         self.act_joint = list(range(12)) if act_joint is None else [int(x) for x in act_joint]
         self.pv = np.array(list(range(6)) + [6 + o for o in self.order])      # canonical i  <->  plant pv[i]
         self.pq = np.array(list(range(7)) + [7 + o for o in self.order])
         self.m = orc.model(model_name)
+        self.backend = backend
+        if backend == "energy":
+            import energy_model as em           # tests/energy_model.py: the independent numpy derivation
+            self._em, self._emodel = em, em.load(model_name)
+        else:
+            assert backend == "oracle"
+
+    # ---- rigid-body terms in canonical order: oracle/ (default) or tests/energy_model.py ("energy": plain FK + Kane
+    # projection, accelerations by Richardson-extrapolated differences along the exact flow; nothing shared with oracle/)
+    def _dyn(self, q, v):
+        if self.backend == "oracle":
+            return orc.calc_dynamics(self.m, q, v)
+        em, t = self._em, self._emodel
+        rich = lambda f, h: (4.0 * f(0.5 * h) - f(h)) / 3.0
+        return em.mass_matrix(t, q), rich(lambda h: em.bias_term(t, q, v, h), 2e-3), em.gravity_term(t, q)
+
+    def _foot(self, q, v, foot):
+        if self.backend == "oracle":
+            return orc.foot_quantities(self.m, q, v, foot)
+        em, t = self._em, self._emodel
+        f = em.bodies(t, q)[1][foot]
+        rich = lambda g, h: (4.0 * g(0.5 * h) - g(h)) / 3.0
+        Jd = rich(lambda h: em.foot_jacobian_dot_fd(t, q, v, foot, h), 2e-3)
+        return np.array(f["p"], dtype=float), np.array(f["J"], dtype=float), Jd @ v
+
+    def _body(self, q, v):
+        if self.backend == "oracle":
+            return orc.body_quantities(self.m, q, v)
+        # the task frame is the floating root itself: J = [I 0] in Drake's world-frame base velocities, so Jdot v = 0
+        return self._em.quat_R(q[:4]), np.array(q[4:7], dtype=float), np.hstack([np.eye(6), np.zeros((6, 12))]), np.zeros(6)
 
     def _vec(self, x_c):                 # canonical 18-vector -> plant numbering
         out = np.empty_like(x_c); out[self.pv] = x_c
@@ -87,7 +118,8 @@ class RefPlant:
         return PlantContext()
 
     def ToAutoDiffXd(self):
-        return RefPlant(self.model_name, self.body_frame_name, autodiff=True, order=self.order, act_joint=self.act_joint)
+        return RefPlant(self.model_name, self.body_frame_name, autodiff=True, order=self.order, act_joint=self.act_joint,
+                        backend=self.backend)
 
     def num_positions(self):
         return 19
@@ -141,43 +173,45 @@ class RefPlant:
 
     # -- dynamics
     def CalcMassMatrixViaInverseDynamics(self, ctx):
-        M = np.empty((18, 18)); M[np.ix_(self.pv, self.pv)] = orc.calc_dynamics(self.m, ctx.q, ctx.v)[0]
+        M = np.empty((18, 18)); M[np.ix_(self.pv, self.pv)] = self._dyn(ctx.q, ctx.v)[0]
         return M
 
     def CalcBiasTerm(self, ctx):
-        Cv = orc.calc_dynamics(self.m, ctx.q, ctx.v)[1]
+        Cv = self._dyn(ctx.q, ctx.v)[1]
         if ctx.vD is None:
             return self._vec(Cv)
         assert self.autodiff and ctx.qD is None
         dC = np.zeros((18, 18))
         for j in range(18):
             e = np.zeros(18); e[j] = 1.0
-            dC[:, j] = 0.5 * (orc.calc_dynamics(self.m, ctx.q, ctx.v + e)[1] - orc.calc_dynamics(self.m, ctx.q, ctx.v - e)[1])
+            dC[:, j] = 0.5 * (self._dyn(ctx.q, ctx.v + e)[1] - self._dyn(ctx.q, ctx.v - e)[1])
         return join(self._vec(Cv), self._vec(dC @ ctx.vD))
 
     def CalcGravityGeneralizedForces(self, ctx):
-        return -self._vec(orc.calc_dynamics(self.m, ctx.q, ctx.v)[2])   # the reference flips the sign (basic_controller.py:112)
+        return -self._vec(self._dyn(ctx.q, ctx.v)[2])   # the reference flips the sign (basic_controller.py:112)
 
     # -- frames
     def CalcRelativeTransform(self, ctx, frame_A, frame_B):
         assert frame_A.name == "world" and frame_B.name == self.body_frame_name
-        R, p, _, _ = orc.body_quantities(self.m, ctx.q, ctx.v)
+        R, p, _, _ = self._body(ctx.q, ctx.v)
         return _Pose(R, p)
 
     def CalcJacobianSpatialVelocity(self, ctx, wrt, frame, p_BoBp, frame_A, frame_E):
         assert wrt == JacobianWrtVariable.kV and frame.name == self.body_frame_name and not np.any(p_BoBp)
-        return self._cols(orc.body_quantities(self.m, ctx.q, ctx.v)[2])
+        return self._cols(self._body(ctx.q, ctx.v)[2])
 
     def CalcBiasSpatialAcceleration(self, ctx, wrt, frame, p_BoBp, frame_A, frame_E):
         assert wrt == JacobianWrtVariable.kV and frame.name == self.body_frame_name and not np.any(p_BoBp)
-        return SpatialAcceleration(orc.body_quantities(self.m, ctx.q, ctx.v)[3])
+        return SpatialAcceleration(self._body(ctx.q, ctx.v)[3])
 
     def CalcPointsPositions(self, ctx, frame, p_BQ, frame_A):
         assert not np.any(p_BQ) and frame_A.name == "world"
-        return orc.foot_quantities(self.m, ctx.q, ctx.v, FEET[frame.name])[0].reshape(3, 1)
+        return self._foot(ctx.q, ctx.v, FEET[frame.name])[0].reshape(3, 1)
 
     def _J(self, q, v, foot):
-        return orc.foot_quantities(self.m, q, v, foot)[1]
+        if self.backend == "energy":
+            return np.array(self._em.bodies(self._emodel, q)[1][foot]["J"], dtype=float)
+        return self._foot(q, v, foot)[1]
 
     def CalcJacobianTranslationalVelocity(self, ctx, wrt, frame, p_BoBp, frame_A, frame_E):
         assert wrt == JacobianWrtVariable.kV and not np.any(p_BoBp)
@@ -196,4 +230,4 @@ class RefPlant:
 
     def CalcBiasTranslationalAcceleration(self, ctx, wrt, frame, p_BoBp, frame_A, frame_E):
         assert wrt == JacobianWrtVariable.kV and not np.any(p_BoBp)
-        return orc.foot_quantities(self.m, ctx.q, ctx.v, FEET[frame.name])[2].reshape(3, 1)
+        return self._foot(ctx.q, ctx.v, FEET[frame.name])[2].reshape(3, 1)

@@ -31,6 +31,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.join(HERE, "..", "..")
 sys.path.insert(0, os.path.join(HERE, "..", "fake_pydrake"))
+sys.path.insert(0, os.path.join(HERE, ".."))      # tests/energy_model.py (the "energy" plant backend)
 sys.path.insert(0, ROOT)
 sys.modules["lcm"] = types.ModuleType("lcm")      # import-only stub: use_lcm=False everywhere below
 np.object = object                                # helpers.py:19 uses the alias numpy removed in 1.24
@@ -56,9 +57,9 @@ def trunk_dict(t54, mask):
     return d
 
 
-def run_set(kind, model, q, v, tg, mask, mu=None, mass_scale=None, order=None, act_joint=None):
+def run_set(kind, model, q, v, tg, mask, mu=None, mass_scale=None, order=None, act_joint=None, backend="oracle"):
     """q, v in CANONICAL joint order; `order` / `act_joint`: the plant's own numbering (refplant.RefPlant)."""
-    plant = fake.RefPlant(model, body_frame="body", order=order, act_joint=act_joint)   # "body": basic_controller.py:65
+    plant = fake.RefPlant(model, body_frame="body", order=order, act_joint=act_joint, backend=backend)   # "body": basic_controller.py:65
     if order is not None:
         qd, vd_ = q.copy(), v.copy()
         for j in range(12):
@@ -130,5 +131,21 @@ for name, kind, n in (("cfg2_id", "id", 8), ("cfg3_mptc", "mptc", 8), ("cfg4_any
         gold[pn + "_" + k] = a
     e = np.abs(r["tau"] - z["tau"][:, :n][ACT]).max(0) / np.maximum(np.abs(z["tau"][:, :n]).max(0), 1e-3)
     print("%-18s %-4s n=%2d  permuted plant, tau vs oracle[act]: max rel %.2e" % (pn, kind, n, e.max()))
+# NOTHING SHARED: the same reference code over a plant whose rigid-body terms come from tests/energy_model.py (plain FK +
+# Kane projection, numerically differentiated twists) instead of oracle/ -- reference law code + independent dynamics +
+# independent solver.  Looser by construction (finite differences inside the dynamics): tests allow 1e-5.
+for name, kind, n in (("cfg2_id", "id", 6), ("cfg3_mptc", "mptc", 6), ("cfg4_anymal_mptc", "mptc", 3), ("cfg3_clf", "clf", 3),
+                      ("cfg3_pc", "pc", 3)):
+    z = np.load(os.path.join(HERE, name + ".npz"))
+    q, v, tg, mk = z["q"][:, :n], z["v"][:, :n], z["targets"][:, :n], z["mask"][:n]
+    r = run_set(kind, str(z["model"]), q, v, tg, mk, backend="energy")
+    pn = "indep_" + name
+    gold[pn + "_kind"] = kind; gold[pn + "_model"] = str(z["model"])
+    gold[pn + "_q"], gold[pn + "_v"], gold[pn + "_targets"], gold[pn + "_mask"] = q, v, tg, mk
+    gold[pn + "_mu"] = np.zeros(0); gold[pn + "_mass_scale"] = np.zeros(0)
+    for k, a in r.items():
+        gold[pn + "_" + k] = a
+    e = np.abs(r["tau"] - z["tau"][:, :n]).max(0) / np.maximum(np.abs(z["tau"][:, :n]).max(0), 1e-3)
+    print("%-22s %-4s n=%2d  independent dynamics, tau vs oracle: max rel %.2e  median %.2e" % (pn, kind, n, e.max(), np.median(e)))
 np.savez_compressed(os.path.join(HERE, "reference_law_golden.npz"), **gold)
 print("wrote reference_law_golden.npz")
