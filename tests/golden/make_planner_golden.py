@@ -24,6 +24,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "fake_pydrake"))
+sys.path.insert(0, os.path.join(HERE, "..", ".."))      # the fake's plant module imports oracle/ (unused by the planners)
 sys.modules["lcm"] = types.ModuleType("lcm")          # import-only stub (see the docstring)
 sys.path.insert(0, "/root/reference")
 import pydrake.all as fake                              # noqa: E402
@@ -117,5 +118,5 @@ gold["towr_u2_max"] = np.float64(tp.u2_max)
 for k, v in stack(snaps).items():
     gold["towr_" + k] = v
 
-np.savez_compressed(os.path.join(HERE, "planner_golden.npz"), **gold)
+np.savez_compressed(os.path.join(os.environ.get("GOLDEN_OUT", HERE), "planner_golden.npz"), **gold)   # GOLDEN_OUT: tests/test_fixture_freshness.py
 print("wrote planner_golden.npz:", len(gold), "arrays,", len(times), "TOWR query times, u2_max =", tp.u2_max)

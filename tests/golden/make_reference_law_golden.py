@@ -147,5 +147,5 @@ for name, kind, n in (("cfg2_id", "id", 6), ("cfg3_mptc", "mptc", 6), ("cfg4_any
         gold[pn + "_" + k] = a
     e = np.abs(r["tau"] - z["tau"][:, :n]).max(0) / np.maximum(np.abs(z["tau"][:, :n]).max(0), 1e-3)
     print("%-22s %-4s n=%2d  independent dynamics, tau vs oracle: max rel %.2e  median %.2e" % (pn, kind, n, e.max(), np.median(e)))
-np.savez_compressed(os.path.join(HERE, "reference_law_golden.npz"), **gold)
+np.savez_compressed(os.path.join(os.environ.get("GOLDEN_OUT", HERE), "reference_law_golden.npz"), **gold)   # GOLDEN_OUT: tests/test_fixture_freshness.py
 print("wrote reference_law_golden.npz")
