@@ -131,6 +131,38 @@ for name, kind, n in (("cfg2_id", "id", 8), ("cfg3_mptc", "mptc", 8), ("cfg4_any
         gold[pn + "_" + k] = a
     e = np.abs(r["tau"] - z["tau"][:, :n][ACT]).max(0) / np.maximum(np.abs(z["tau"][:, :n]).max(0), 1e-3)
     print("%-18s %-4s n=%2d  permuted plant, tau vs oracle[act]: max rel %.2e" % (pn, kind, n, e.max()))
+# the reference's own experiments: simulate.py:171-179 initial state with the dictionaries its BasicTrunkPlanner produces
+# for its scenarios (planner_golden.npz, made by make_planner_golden.py from planners/simple.py) -- planner code and
+# controller code of the reference chained, as simulate.py wires them
+pg = np.load(os.path.join(HERE, "planner_golden.npz"))
+PKEYS = list(BODY) + [pre + f for f in FEET for pre in ("p_", "pd_", "pdd_")]
+
+
+def planner_case(prefix, i=None):
+    pick = (lambda a: a) if i is None else (lambda a: a[i])
+    t = np.concatenate([pick(pg[prefix + k]) for k in PKEYS])          # include/wbc.h row order == PKEYS order
+    return t, sum(1 << b for b, c in enumerate(pick(pg[prefix + "contact_states"])) if c)
+
+
+cases = [planner_case("basic_standing_"), planner_case("basic_edge_"), planner_case("basic_raisefoot_", 1),
+         planner_case("basic_raisefoot_", 4), planner_case("basic_orientation_", 3), planner_case("basic_orientation_", 6)]
+q0 = np.array([1.0, 0, 0, 0, 0, 0, 0.3] + [0.0, -0.8, 1.6] * 4); v0 = np.zeros(18)     # simulate.py:171-179
+for kind in ("id", "mptc", "pc", "clf"):
+    n = len(cases)
+    q = np.tile(q0[:, None], (1, n)); v = np.tile(v0[:, None], (1, n))
+    tg = np.stack([c[0] for c in cases], axis=1); mk = np.array([c[1] for c in cases], np.uint8)
+    r = run_set(kind, "mini_cheetah", q, v, tg, mk)
+    pn = "scen_" + kind
+    gold[pn + "_kind"] = kind; gold[pn + "_model"] = "mini_cheetah"
+    gold[pn + "_q"], gold[pn + "_v"], gold[pn + "_targets"], gold[pn + "_mask"] = q, v, tg, mk
+    gold[pn + "_mu"] = np.zeros(0); gold[pn + "_mass_scale"] = np.zeros(0)
+    for k, a in r.items():
+        gold[pn + "_" + k] = a
+    tau_o, _, st_o = orc.step_batch(kind, orc.model("mini_cheetah"), orc.params(kind), q, v, tg, mk)
+    e = np.abs(r["tau"] - tau_o).max(0) / np.maximum(np.abs(tau_o).max(0), 1e-3)
+    print("%-22s %-4s n=%2d  reference scenarios at q0, tau vs oracle: max rel %.2e   active rows %s" %
+          (pn, kind, n, e.max(), r["nactive"].tolist()))
+
 # NOTHING SHARED: the same reference code over a plant whose rigid-body terms come from tests/energy_model.py (plain FK +
 # Kane projection, numerically differentiated twists) instead of oracle/ -- reference law code + independent dynamics +
 # independent solver.  Looser by construction (finite differences inside the dynamics): tests allow 1e-5.

@@ -17,6 +17,8 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 SETS = ["cfg2_id", "cfg3_id", "cfg3_mptc", "cfg4_anymal_mptc", "cfg5_rand_mptc", "cfg3_pc", "cfg2_pc", "cfg3_clf", "cfg2_clf",
         "masks16_id", "masks16_mptc", "masks16_pc", "masks16_clf",
+        # simulate.py's initial state with the dictionaries of the reference's planner scenarios (planner + controller chained)
+        "scen_id", "scen_mptc", "scen_pc", "scen_clf",
         # the same reference code over a plant backed by tests/energy_model.py instead of oracle/: nothing shared at all
         "indep_cfg2_id", "indep_cfg3_mptc", "indep_cfg4_anymal_mptc", "indep_cfg3_clf", "indep_cfg3_pc"]
 PERM_SETS = ["perm_cfg2_id", "perm_cfg3_mptc", "perm_cfg4_anymal_mptc"]   # plant with its own joint / actuator numbering
