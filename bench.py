@@ -326,8 +326,9 @@ def run_rank(a):
     sync(); barrier(); sync()
     t0 = time.perf_counter()
     # exactly K steps; HIP events on the launch stream bracket the same K launches
-    ms_per_launch = bound.time_steps(a.steps)
+    bound.time_steps(a.steps, wait=False)        # K launches + the two events queued; ONE host wait follows, in stats()
     st, per_rank, seen = wstats.all_gather_stats(ctrl.stats(), device=cdev)   # end-of-rollout statistics (RCCL when world > 1)
+    ms_per_launch = bound.time_steps_result()    # the events completed before the statistics did: no second wait
     sync(); barrier(); sync()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -118,11 +118,15 @@ int wbc_step(wbc_handle h, int n, int ld, const double* q, const double* v, cons
 int wbc_sync(wbc_handle h);
 
 /* Runs `steps` back-to-back wbc_step launches bracketed by HIP events on the handle's stream
- * and returns the average milliseconds per launch (device time).  Blocks. */
+ * and returns the average milliseconds per launch (device time).  Blocks -- unless ms_per_step is
+ * NULL: then the launches and both events are only queued, and wbc_time_steps_result() reports the
+ * time once the caller has waited for the stream anyway (e.g. through wbc_stats_get). */
 int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, const double* v,
                    const double* targets, const uint8_t* contact_mask, const double* mu,
                    const double* mass_scale, double* tau, double* metrics, int32_t* status,
                    float* ms_per_step);
+
+int wbc_time_steps_result(wbc_handle h, float* ms_per_step);
 
 /* The same `steps` launches with one HIP event between every two of them: ms_each[s] = device time of launch s
  * (for the median / p10 / p90 of SURVEY 8d's protocol; the events add ~1 us between launches, so the

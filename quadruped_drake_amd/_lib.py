@@ -15,7 +15,7 @@ DEVICE_PTRS, HOST_PTRS = 0, 1
 
 # every symbol include/wbc.h declares
 SYMBOLS = ["wbc_last_error", "wbc_version", "wbc_params_default", "wbc_create", "wbc_destroy", "wbc_set_stream",
-           "wbc_step", "wbc_sync", "wbc_time_steps", "wbc_time_steps_each", "wbc_stats_get", "wbc_stats_reset", "wbc_set_variant", "wbc_set_vdot_output", "wbc_integrate", "wbc_rollout",
+           "wbc_step", "wbc_sync", "wbc_time_steps", "wbc_time_steps_result", "wbc_time_steps_each", "wbc_stats_get", "wbc_stats_reset", "wbc_set_variant", "wbc_set_vdot_output", "wbc_integrate", "wbc_rollout",
            "wbc_kernel_info", "wbc_variant_for", "wbc_trunk_state_decode", "wbc_trunk_state_to_targets", "wbc_traj_create",
            "wbc_traj_destroy", "wbc_traj_lookup"]
 
@@ -69,6 +69,7 @@ def lib():
         l.wbc_step.argtypes = step_args
         l.wbc_sync.argtypes = [C.c_void_p]
         l.wbc_time_steps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.POINTER(C.c_float)]
+        l.wbc_time_steps_result.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.wbc_time_steps_each.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.POINTER(C.c_float)]
         l.wbc_stats_get.argtypes = [C.c_void_p, C.POINTER(WbcStats)]
         l.wbc_stats_reset.argtypes = [C.c_void_p]

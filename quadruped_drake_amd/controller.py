@@ -182,6 +182,8 @@ class BatchedController:
     def bind(self, q, v, targets, contact_mask, mu=None, mass_scale=None, out=None):
         """Validate the tensors ONCE and return a callable bundle for repeated ticks on the same buffers (a control loop
         steps the same device arrays every tick; the per-call checks of step() cost ~10 us of Python each)."""
+        if self.host_ptrs:
+            raise ValueError("bind(): device-pointer handles only (host-pointer steps stage and synchronise every call)")
         n, keep, ptrs, outs = self._args(q, v, targets, contact_mask, mu, mass_scale, out)
         ctrl = self
 
@@ -194,10 +196,16 @@ class BatchedController:
                 _lib.check(ctrl._L.wbc_step(ctrl._h, n, n, *ptrs))
                 return outs
 
-            def time_steps(self, steps):
+            def time_steps(self, steps, wait=True):
+                """wait=False only queues the launches and their two events; time_steps_result() reads them later."""
                 ms = C.c_float(0)
                 ctrl._bind_stream()
-                _lib.check(ctrl._L.wbc_time_steps(ctrl._h, int(steps), n, n, *ptrs, C.byref(ms)))
+                _lib.check(ctrl._L.wbc_time_steps(ctrl._h, int(steps), n, n, *ptrs, C.byref(ms) if wait else None))
+                return ms.value if wait else None
+
+            def time_steps_result(self):
+                ms = C.c_float(0)
+                _lib.check(ctrl._L.wbc_time_steps_result(ctrl._h, C.byref(ms)))
                 return ms.value
 
         return Bound()

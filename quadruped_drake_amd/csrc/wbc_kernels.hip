@@ -580,6 +580,7 @@ struct wbc_handle_s {
   StatsDev* d_stats;
   StatsDev* h_stats;  // pinned, device-mapped: the reduce kernel writes the totals straight into host memory
   hipEvent_t ev0, ev1;
+  int timed_steps;  // launches between ev0 and ev1 of the last wbc_time_steps call (0: none yet)
   std::vector<hipEvent_t> evs;  // per-launch events of wbc_time_steps_each (grown on demand, outside any timed region)
   // staging buffers for WBC_HOST_PTRS
   double* d_vdot;  // optional [18][ld] output of the generalized accelerations (wbc_set_vdot_output)
@@ -785,7 +786,7 @@ int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, cons
                    float* ms_per_step) {
   int rc = check_step_args(h, n, ld, q, v, targets, contact_mask, tau);
   if (rc) return rc;
-  if (steps <= 0 || !ms_per_step) return misuse("wbc_time_steps: steps must be positive and ms_per_step non-null");
+  if (steps <= 0) return misuse("wbc_time_steps: steps must be positive");
   if (h->flags & WBC_HOST_PTRS) return misuse("wbc_time_steps: needs a WBC_DEVICE_PTRS handle (inputs resident in HBM)");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
@@ -794,10 +795,19 @@ int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, cons
     if (rc) return rc;
   }
   HIP_TRY(hipEventRecord(h->ev1, h->stream));
+  h->timed_steps = steps;
+  if (!ms_per_step) return 0;   // asynchronous form: wbc_time_steps_result() reads the events later
+  return wbc_time_steps_result(h, ms_per_step);
+}
+
+int wbc_time_steps_result(wbc_handle h, float* ms_per_step) {
+  if (!h || !ms_per_step) return misuse("wbc_time_steps_result: null argument");
+  if (h->timed_steps <= 0) return misuse("wbc_time_steps_result: no wbc_time_steps call to report");
+  HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipEventSynchronize(h->ev1));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
-  *ms_per_step = ms / steps;
+  *ms_per_step = ms / h->timed_steps;
   return 0;
 }
 

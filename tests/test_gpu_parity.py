@@ -127,6 +127,10 @@ def test_bound_buffers_tick_like_step():
     tau2.zero_()
     assert bound.time_steps(3) > 0.0
     assert torch.equal(tau, bound.outputs[0])
+    tau2.zero_()
+    assert bound.time_steps(3, wait=False) is None          # queued only; the caller's next wait covers it
+    ctrl.stats()
+    assert bound.time_steps_result() > 0.0 and torch.equal(tau, bound.outputs[0])
     with pytest.raises(ValueError):
         ctrl.bind(q.float(), v, tg, mask)
     ctrl.close()
