@@ -206,6 +206,33 @@ int wbc_traj_destroy(wbc_traj t);
 int wbc_traj_lookup(wbc_traj t, void* hip_stream, int n, int ld, const double* time, double* targets,
                     uint8_t* contact_mask);
 
+/* ------------------------------------------------------------------------------------------
+ * The robot-side wire format of the reference's use_lcm path (controllers/basic_controller.py:52-61,79-87,289-314):
+ * `robot_state_control_lcmt` (lcm_types/robot_state_control_lcmt.lcm: float q[19], v[18], tau[12]) -- 204 bytes,
+ * 8-byte fingerprint rotl1(0xbe14089c923ad667) then 49 big-endian IEEE floats
+ * (lcm_types/cheetahlcm/robot_state_control_lcmt.py:28-79).  States arrive on "robot_current_state" in the plant's
+ * own joint order (exactly the rows wbc_step takes with q_perm); torques leave on "robot_control_input" as
+ * (S'u)[-12:] -- the actuator-order torques re-indexed to the plant's joint order (basic_controller.py:310-313),
+ * q and v of that message left zero. */
+#define WBC_ROBOT_STATE_BYTES 204
+typedef struct {
+  float q[19], v[18], tau[12];
+} wbc_robot_state;
+/* host, one message: 0 on success; -1 short buffer / null; -3 fingerprint mismatch ("Decode error", :51-52) */
+int wbc_robot_state_decode(const uint8_t* buf, size_t len, wbc_robot_state* out);
+/* host, one message: bytes written (204) or -1 */
+int wbc_robot_state_encode(const wbc_robot_state* in, uint8_t* buf, size_t cap);
+/* device, batched: n messages back to back in `msgs` (device, 4-byte aligned) -> q[19][ld], v[18][ld] (float -> double
+ * is exact); ok[i] (nullable) = 1 decoded / 0 fingerprint mismatch (that robot's columns are left untouched).
+ * Asynchronous on `hip_stream`. */
+int wbc_robot_states_unpack(int device, void* hip_stream, int n, int ld, const uint8_t* msgs, double* q, double* v,
+                            uint8_t* ok);
+/* device, batched: tau[12][ld] in ACTUATOR order (what wbc_step wrote) -> n "robot_control_input" messages.
+ * q_perm / act_perm: host int[12], the handle's model permutations (NULL = identity):
+ * message.tau[q_perm[act_perm[k]]] = (float) tau[k].  Asynchronous on `hip_stream`. */
+int wbc_robot_controls_pack(int device, void* hip_stream, int n, int ld, const double* tau, const int* q_perm,
+                            const int* act_perm, uint8_t* msgs);
+
 #ifdef __cplusplus
 }
 #endif

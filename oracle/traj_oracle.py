@@ -69,3 +69,25 @@ def integrate(q, v, vd, dt):
     q[4:7] += dt * v[3:6]
     q[7:] += dt * v[6:]
     return q, v
+
+
+# ---- robot_state_control_lcmt (lcm_types/cheetahlcm/robot_state_control_lcmt.py:28-79), the use_lcm path of
+# controllers/basic_controller.py:79-87,289-314
+RS_FINGERPRINT = struct.pack(">Q", ((0xbe14089c923ad667 << 1) & 0xffffffffffffffff) + (0xbe14089c923ad667 >> 63))
+
+
+def robot_state_decode(buf):
+    """-> (q[19], v[18], tau[12]) as the float32 values on the wire, widened to float64 (np.asarray(msg.q), :85-86)"""
+    if buf[:8] != RS_FINGERPRINT:
+        raise ValueError("Decode error")
+    x = np.array(struct.unpack_from(">49f", buf, 8), dtype=np.float64)
+    return x[:19], x[19:37], x[37:]
+
+
+def robot_control_message(u, order, act_joint):
+    """basic_controller.py:308-314: msg.tau = (S'u)[-12:] with S' = MakeActuationMatrix() of a plant whose canonical joint j
+    sits at index order[j] and whose actuator k drives canonical joint act_joint[k]; q, v of the message stay zero."""
+    t = np.zeros(12)
+    for k in range(12):
+        t[order[act_joint[k]]] = u[k]
+    return RS_FINGERPRINT + struct.pack(">37f", *([0.0] * 37)) + struct.pack(">12f", *t)

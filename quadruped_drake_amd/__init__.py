@@ -6,4 +6,5 @@ callers that feed the path), trajectory.py (trunk_state_t decode, device-side ta
 batches of BASELINE.json's configs), stats.py (multi-GPU shard + RCCL statistics reduce)."""
 from .controller import IDController, MPTCController, PCController, CLFController, BatchedController, SolverError, pack_trunk_input, load_model, make_leaf_system  # noqa
 from . import workloads  # noqa
+from . import lcm_io  # noqa
 from .planners import BasicTrunkPlanner, TowrTrunkPlanner, scenario_targets, scenario_trajectory, unpack_trunk_input  # noqa

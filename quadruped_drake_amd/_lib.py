@@ -17,7 +17,8 @@ DEVICE_PTRS, HOST_PTRS = 0, 1
 SYMBOLS = ["wbc_last_error", "wbc_version", "wbc_params_default", "wbc_create", "wbc_destroy", "wbc_set_stream",
            "wbc_step", "wbc_sync", "wbc_time_steps", "wbc_time_steps_result", "wbc_time_steps_each", "wbc_stats_get", "wbc_stats_reset", "wbc_set_variant", "wbc_set_vdot_output", "wbc_integrate", "wbc_rollout",
            "wbc_kernel_info", "wbc_variant_for", "wbc_trunk_state_decode", "wbc_trunk_state_to_targets", "wbc_traj_create",
-           "wbc_traj_destroy", "wbc_traj_lookup"]
+           "wbc_traj_destroy", "wbc_traj_lookup", "wbc_robot_state_decode", "wbc_robot_state_encode",
+           "wbc_robot_states_unpack", "wbc_robot_controls_pack"]
 
 
 class WbcModel(C.Structure):
@@ -42,6 +43,10 @@ class WbcTrunkState(C.Structure):
                 ("base_rpy", C.c_double * 3), ("base_rpyd", C.c_double * 3), ("base_rpydd", C.c_double * 3),
                 ("foot_p", (C.c_double * 3) * 4), ("foot_pd", (C.c_double * 3) * 4), ("foot_pdd", (C.c_double * 3) * 4),
                 ("contact", C.c_uint8 * 4), ("foot_f", (C.c_double * 3) * 4)]
+
+
+class WbcRobotState(C.Structure):
+    _fields_ = [("q", C.c_float * 19), ("v", C.c_float * 18), ("tau", C.c_float * 12)]
 
 
 class WbcError(RuntimeError):
@@ -85,6 +90,11 @@ def lib():
                                       C.POINTER(C.c_void_p)]
         l.wbc_traj_destroy.argtypes = [C.c_void_p]
         l.wbc_traj_lookup.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.wbc_robot_state_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(WbcRobotState)]
+        l.wbc_robot_state_encode.argtypes = [C.POINTER(WbcRobotState), C.c_char_p, C.c_size_t]
+        l.wbc_robot_states_unpack.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        l.wbc_robot_controls_pack.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                              C.c_void_p]
         for s in SYMBOLS:
             getattr(l, s)
         _lib = l

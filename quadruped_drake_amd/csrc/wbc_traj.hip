@@ -1,6 +1,7 @@
-// wbc_traj.hip -- callers of the hot path: trunk_state_t wire decode and the
-// device-side nearest-timestamp target lookup of planners/towr.py:92-148.  Byte/index work:
-// bit-exact against the reference's own encoder (tests/golden/trunk_state_*).
+// wbc_traj.hip -- callers of the hot path: trunk_state_t wire decode, the device-side
+// nearest-timestamp target lookup of planners/towr.py:92-148, and the robot-side wire format of the use_lcm path
+// (robot_state_control_lcmt: batched unpack / pack on the device).  Byte/index work: bit-exact against the
+// reference's own encoders (tests/golden/trunk_state_*, robot_state_*).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -50,6 +51,43 @@ __global__ void traj_lookup_kernel(int n, int ld, wbc::TrajDev T, const double* 
   for (int r = 0; r < 54; r++) targets[(size_t)r * ld + i] = src[r];
   contact_mask[i] = mk;
 }
+
+// ---- robot_state_control_lcmt (lcm_types/cheetahlcm/robot_state_control_lcmt.py:62-72): hash = rotl1(0xbe14089c923ad667)
+constexpr uint64_t kRsBase = 0xbe14089c923ad667ull;
+constexpr uint64_t kRsFingerprint = (kRsBase << 1) + (kRsBase >> 63);
+constexpr int kRsWords = WBC_ROBOT_STATE_BYTES / 4;   // 51: 2 fingerprint words + 19 + 18 + 12 floats
+
+__host__ __device__ inline uint32_t bswap32(uint32_t x) {
+  return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24);
+}
+
+// thread (i, r): field r (0..36 = q then v) of message i -> SoA row r, column i
+__global__ void robot_states_unpack_kernel(int n, int ld, const uint32_t* __restrict__ w, double* __restrict__ q,
+                                           double* __restrict__ v, uint8_t* __restrict__ ok) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (i >= n) return;
+  const uint32_t* m = w + (size_t)i * kRsWords;
+  const bool good = bswap32(m[0]) == (uint32_t)(kRsFingerprint >> 32) && bswap32(m[1]) == (uint32_t)kRsFingerprint;
+  if (r == 0 && ok) ok[i] = good ? 1 : 0;
+  if (!good) return;
+  const uint32_t bits = bswap32(m[2 + r]);
+  const double x = (double)__uint_as_float(bits);
+  if (r < 19) q[(size_t)r * ld + i] = x;
+  else v[(size_t)(r - 19) * ld + i] = x;
+}
+
+struct RsSrc { int k[12]; };   // message.tau[jd] = tau[k[jd]]
+
+// thread (i, word): word 0/1 fingerprint, 2..38 zeros (q, v), 39..50 torques in the plant's joint order
+__global__ void robot_controls_pack_kernel(int n, int ld, const double* __restrict__ tau, RsSrc src, uint32_t* __restrict__ w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (i >= n) return;
+  uint32_t out = 0u;
+  if (c == 0) out = (uint32_t)(kRsFingerprint >> 32);
+  else if (c == 1) out = (uint32_t)kRsFingerprint;
+  else if (c >= 39) out = __float_as_uint((float)tau[(size_t)src.k[c - 39] * ld + i]);   // round to nearest even, like struct.pack('>f')
+  w[(size_t)i * kRsWords + c] = bswap32(out);
+}
 }  // namespace
 
 struct wbc_traj_s {
@@ -78,6 +116,68 @@ int wbc_trunk_state_decode(const uint8_t* buf, size_t len, wbc_trunk_state* out)
   for (int f = 0; f < 4; f++) out->contact[f] = (*p++) != 0;
   for (int f = 0; f < 4; f++) p = rd3(p, out->foot_f[f]);
   return (p - buf) == WBC_TRUNK_STATE_BYTES ? 0 : -1;
+}
+
+int wbc_robot_state_decode(const uint8_t* buf, size_t len, wbc_robot_state* out) {
+  if (!buf || !out || len < WBC_ROBOT_STATE_BYTES) return -1;
+  uint64_t fp = 0;
+  for (int i = 0; i < 8; i++) fp = (fp << 8) | buf[i];
+  if (fp != kRsFingerprint) return -3;
+  float* dst = out->q;   // q[19], v[18], tau[12] are contiguous floats
+  static_assert(sizeof(wbc_robot_state) == 49 * sizeof(float), "robot_state layout");
+  for (int k = 0; k < 49; k++) {
+    const uint8_t* p = buf + 8 + 4 * k;
+    const uint32_t u = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+    memcpy(dst + k, &u, 4);
+  }
+  return 0;
+}
+
+int wbc_robot_state_encode(const wbc_robot_state* in, uint8_t* buf, size_t cap) {
+  if (!in || !buf || cap < WBC_ROBOT_STATE_BYTES) return -1;
+  for (int i = 0; i < 8; i++) buf[i] = (uint8_t)(kRsFingerprint >> (56 - 8 * i));
+  const float* src = in->q;
+  for (int k = 0; k < 49; k++) {
+    uint32_t u;
+    memcpy(&u, src + k, 4);
+    uint8_t* p = buf + 8 + 4 * k;
+    p[0] = (uint8_t)(u >> 24); p[1] = (uint8_t)(u >> 16); p[2] = (uint8_t)(u >> 8); p[3] = (uint8_t)u;
+  }
+  return WBC_ROBOT_STATE_BYTES;
+}
+
+int wbc_robot_states_unpack(int device, void* hip_stream, int n, int ld, const uint8_t* msgs, double* q, double* v,
+                            uint8_t* ok) {
+  if (n < 0 || ld < n || (n > 0 && (!msgs || !q || !v))) return tmisuse("wbc_robot_states_unpack: bad argument");
+  if (((uintptr_t)msgs & 3u) != 0) return tmisuse("wbc_robot_states_unpack: msgs must be 4-byte aligned");
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(robot_states_unpack_kernel, dim3((n + 255) / 256, 37), dim3(256), 0, (hipStream_t)hip_stream, n, ld,
+                     reinterpret_cast<const uint32_t*>(msgs), q, v, ok);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int wbc_robot_controls_pack(int device, void* hip_stream, int n, int ld, const double* tau, const int* q_perm,
+                            const int* act_perm, uint8_t* msgs) {
+  if (n < 0 || ld < n || (n > 0 && (!tau || !msgs))) return tmisuse("wbc_robot_controls_pack: bad argument");
+  if (((uintptr_t)msgs & 3u) != 0) return tmisuse("wbc_robot_controls_pack: msgs must be 4-byte aligned");
+  RsSrc src;
+  bool seen[12] = {false};
+  for (int k = 0; k < 12; k++) {
+    const int j = act_perm ? act_perm[k] : k;                       // canonical joint driven by actuator k
+    if (j < 0 || j >= 12) return tmisuse("wbc_robot_controls_pack: act_perm must be a permutation of 0..11");
+    const int jd = q_perm ? q_perm[j] : j;                          // its index in the plant's joint order
+    if (jd < 0 || jd >= 12 || seen[jd]) return tmisuse("wbc_robot_controls_pack: q_perm / act_perm must be permutations of 0..11");
+    seen[jd] = true;
+    src.k[jd] = k;
+  }
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(robot_controls_pack_kernel, dim3((n + 255) / 256, kRsWords), dim3(256), 0, (hipStream_t)hip_stream, n, ld,
+                     tau, src, reinterpret_cast<uint32_t*>(msgs));
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 int wbc_trunk_state_to_targets(const wbc_trunk_state* s, double* t, uint8_t* contact_mask) {

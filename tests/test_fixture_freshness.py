@@ -13,7 +13,8 @@ pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/controllers")
 
 
 @pytest.mark.parametrize("script,fixture", [("make_reference_law_golden.py", "reference_law_golden.npz"),
-                                            ("make_planner_golden.py", "planner_golden.npz")])
+                                            ("make_planner_golden.py", "planner_golden.npz"),
+                                            ("make_robot_state_golden.py", "robot_state_expected.npz")])
 def test_generator_reproduces_the_committed_fixture(tmp_path, script, fixture):
     env = dict(os.environ, GOLDEN_OUT=str(tmp_path))
     subprocess.run([sys.executable, os.path.join(HERE, "golden", script)], check=True, env=env, capture_output=True, timeout=600)
