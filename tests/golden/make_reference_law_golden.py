@@ -163,6 +163,38 @@ for kind in ("id", "mptc", "pc", "clf"):
     print("%-22s %-4s n=%2d  reference scenarios at q0, tau vs oracle: max rel %.2e   active rows %s" %
           (pn, kind, n, e.max(), r["nactive"].tolist()))
 
+# closed loop: the reference's planner scenario (RaiseFoot across its contact switch at t > 1) -> the reference's
+# controller code -> the forward step of include/wbc.h (oracle/traj_oracle.integrate, semi-implicit Euler on the QP's own
+# accelerations), 60 ticks.  Pins the chain lookup -> tick -> integrate of wbc_rollout against the executed reference.
+from oracle import traj_oracle as to_      # noqa: E402
+sys.path.insert(0, ROOT)
+from planners.simple import BasicTrunkPlanner   # noqa: E402  (reference code)
+bp = BasicTrunkPlanner({"trunk": 0, "lf": 1, "rf": 2, "lh": 3, "rh": 4})
+for kind, dt, t_start in (("id", 5e-3, 0.85), ("mptc", 1e-3, 0.97)):
+    plant = fake.RefPlant("mini_cheetah", body_frame="body")
+    ctrl = LAWS[kind](plant, dt)
+    steps = 60
+    # start from a state already shifted over the support triangle (what the scenario has reached by then)
+    q = q0.copy(); q[4:7] = [-0.1, 0.05, 0.3]; v = v0.copy()
+    Q, V, T, TAU = [q.copy()], [v.copy()], [], []
+    for k in range(steps):
+        t = t_start + k * dt
+        bp.RaiseFoot(t)
+        d = dict(bp.output_dict)
+        ctx = ctrl.CreateDefaultContext()
+        ctrl.get_input_port(0).FixValue(ctx, np.concatenate([q, v]))
+        ctrl.get_input_port(1).FixValue(ctx, d)
+        tau = ctrl.get_output_port(0).Eval(ctx)
+        vd = OsqpSolver.last["x"][:18]
+        qn, vn = to_.integrate(q[:, None], v[:, None], vd[:, None], dt)
+        q, v = qn[:, 0], vn[:, 0]
+        Q.append(q.copy()); V.append(v.copy()); T.append(t); TAU.append(np.array(tau))
+    pn = "closedloop_" + kind
+    gold[pn + "_dt"] = dt; gold[pn + "_times"] = np.array(T)
+    gold[pn + "_q"] = np.array(Q).T; gold[pn + "_v"] = np.array(V).T; gold[pn + "_tau"] = np.array(TAU).T
+    print("%-22s %d ticks from t = %.3f, dt = %g: RF foot contact %s -> %s, |v|max %.3f" %
+          (pn, steps, t_start, dt, True, bool(d["contact_states"][1]), np.abs(np.array(V)).max()))
+
 # NOTHING SHARED: the same reference code over a plant whose rigid-body terms come from tests/energy_model.py (plain FK +
 # Kane projection, numerically differentiated twists) instead of oracle/ -- reference law code + independent dynamics +
 # independent solver.  Looser by construction (finite differences inside the dynamics): tests allow 1e-5.

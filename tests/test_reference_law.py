@@ -141,3 +141,55 @@ def test_permuted_plant_hip_path(name):
     tau, st = tau.cpu().numpy(), st.cpu().numpy()
     ctrl.close()
     assert (st == 0).all() and rel(tau, g["tau"]).max() < TAU_TOL
+
+
+def _closed(kind):
+    z = np.load(os.path.join(HERE, "golden", "reference_law_golden.npz"))
+    p = "closedloop_%s_" % kind
+    return float(z[p + "dt"]), z[p + "times"], z[p + "q"], z[p + "v"], z[p + "tau"]
+
+
+@pytest.mark.parametrize("kind", ["id", "mptc"])
+def test_closed_loop_oracle_follows_the_executed_reference(kind):
+    """Reference planner scenario (RaiseFoot across its contact switch) -> reference controller code -> forward step,
+    60 ticks (make_reference_law_golden.py): the oracle's tick + the numpy integrator retrace the same trajectory."""
+    from oracle import oracle_py as orc
+    from oracle import traj_oracle as to
+    from quadruped_drake_amd.planners import scenario_targets
+    dt, T, Q, V, TAU = _closed(kind)
+    m, p = orc.model("mini_cheetah"), orc.params(kind)
+    q, v = Q[:, 0].copy(), V[:, 0].copy()
+    for k, t in enumerate(T):
+        tg, mk = scenario_targets("raise_foot", [t])
+        tau, met, st, qp = orc.control_law(kind, m, p, q, v, tg[:, 0], [(int(mk[0]) >> b) & 1 for b in range(4)], want_qp=True)
+        assert st == 0 and np.abs(tau - TAU[:, k]).max() < 1e-5 * max(np.abs(TAU[:, k]).max(), 1e-3), (kind, k)
+        qn, vn = to.integrate(q[:, None], v[:, None], qp["x"][:18][:, None], dt)
+        q, v = qn[:, 0], vn[:, 0]
+        assert np.abs(q - Q[:, k + 1]).max() < 1e-7 and np.abs(v - V[:, k + 1]).max() < 1e-6, (kind, k)
+    assert (T <= 1).any() and (T > 1).any()          # the contact switch lies inside the window
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["id", "mptc"])
+def test_device_rollout_follows_the_executed_reference(kind):
+    """wbc_rollout (stored-trajectory lookup -> tick -> forward step, one persistent launch per chunk) against the same
+    trajectory: the whole closed-loop chain of the device against the reference's executed planner + controller code."""
+    import torch
+    from quadruped_drake_amd import IDController, MPTCController
+    from quadruped_drake_amd.planners import scenario_targets
+    from quadruped_drake_amd.trajectory import TrunkTrajectory
+    dt, T, Q, V, TAU = _closed(kind)
+    tg, mk = scenario_targets("raise_foot", T)
+    traj = TrunkTrajectory(T, np.ascontiguousarray(tg.T), mk, wait_time=0.0, device=0)
+    ctrl = {"id": IDController, "mptc": MPTCController}[kind](max_batch=4, device=0)
+    q = torch.tensor(np.tile(Q[:, :1], (1, 4)), device="cuda:0"); v = torch.tensor(np.tile(V[:, :1], (1, 4)), device="cuda:0")
+    time = torch.full((4,), float(T[0]), dtype=torch.float64, device="cuda:0")
+    for c in range(6):
+        tau, met, st, _, mko = ctrl.rollout(traj, 10, dt, q, v, time); ctrl.sync()
+        k = 10 * (c + 1)
+        assert (st.cpu().numpy() == 0).all()
+        assert np.abs(q.cpu().numpy()[:, 0] - Q[:, k]).max() < 1e-7 and np.abs(v.cpu().numpy()[:, 0] - V[:, k]).max() < 1e-6, (kind, k)
+        assert np.abs(tau.cpu().numpy()[:, 0] - TAU[:, k - 1]).max() < 1e-5 * max(np.abs(TAU[:, k - 1]).max(), 1e-3)
+        assert int(mko.cpu().numpy()[0]) == int(mk[k - 1])
+    assert torch.equal(q[:, 0], q[:, 3])             # the four copies stay identical
+    ctrl.close(); traj.close()
