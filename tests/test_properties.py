@@ -133,3 +133,36 @@ def test_gpu_outputs_satisfy_dynamics_and_friction(seed, kind, mu, scale):
         for l in range(4):
             if (mk[i] >> l) & 1:
                 assert abs(f[l, 0]) <= mu * f[l, 2] + 1e-7 * sc and abs(f[l, 1]) <= mu * f[l, 2] + 1e-7 * sc
+
+
+# ---- wire formats and planner dictionaries (callers of the path): round-trip properties on arbitrary values
+f32 = st.floats(width=32, allow_nan=False, allow_infinity=True)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(f32, min_size=49, max_size=49))
+def test_robot_state_codec_round_trips_bit_for_bit(vals):
+    """robot_state_control_lcmt: C codec == numpy/struct oracle on arbitrary float32 payloads (infinities, zeros of both
+    signs, denormals), and decode(encode(x)) == x."""
+    import struct
+    from oracle import traj_oracle as to
+    from quadruped_drake_amd.lcm_io import decode_robot_state, encode_robot_state
+    x = np.array(vals, dtype=np.float32)
+    b = encode_robot_state(x[:19], x[19:37], x[37:])
+    assert b == to.RS_FINGERPRINT + struct.pack(">49f", *x.tolist())
+    d = decode_robot_state(b)
+    assert np.concatenate([d["q"], d["v"], d["tau"]]).tobytes() == x.tobytes()
+    q, v, tau = to.robot_state_decode(b)
+    assert np.concatenate([q, v, tau]).astype(np.float32).tobytes() == x.tobytes()
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(st.floats(min_value=-1e6, max_value=1e6, allow_nan=False), min_size=54, max_size=54), st.integers(0, 15))
+def test_trunk_dictionary_pack_unpack_are_inverse(vals, mask):
+    from quadruped_drake_amd import pack_trunk_input, unpack_trunk_input
+    t = np.array(vals)
+    d = unpack_trunk_input(t, mask)
+    assert set(d) == {"p_body", "pd_body", "pdd_body", "rpy_body", "rpyd_body", "rpydd_body", "contact_states", "f_cj", "u2_max"} | \
+        {pre + f for f in ("lf", "rf", "lh", "rh") for pre in ("p_", "pd_", "pdd_")}        # the keys of planners/simple.py:45-85
+    t2, m2 = pack_trunk_input(d)
+    assert t2.tobytes() == t.tobytes() and m2 == mask
