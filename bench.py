@@ -357,6 +357,22 @@ def run_rank(a):
                 traffic = ent["bytes_per_launch"]
         except (OSError, ValueError):
             pass
+        # what the issue slots did (same separate-pass PMC file, committed): executed FP64 flops include the arithmetic the
+        # 16-lane mapping replicates on sub-lanes, so they say how busy the ALU was, not how much of it was useful
+        issued = None
+        try:
+            if shard["kind"] == "mptc" and cfg == 3 and n == 4096:
+                with open(os.path.join(ROOT, "profiles", "r02", "hex_pmc.json")) as f:
+                    pc = json.load(f)["counters"]
+                g = lambda k: pc[k]["mean_per_launch"]
+                ex = 64.0 * (2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64"))
+                issued = {"executed_fp64_flops_per_launch": ex, "executed_TFLOPs": ex / sec / 1e12,
+                          "executed_frac_of_peak": ex / sec / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                          "redundancy": ex / (flops * n), "valu_insts_per_wavefront": g("SQ_INSTS_VALU") / g("SQ_WAVES"),
+                          "mfma_insts": g("SQ_INSTS_MFMA"),
+                          "source": "profiles/r02/hex_pmc.json (rocprofv3 --pmc, separate passes of this command)"}
+        except (OSError, ValueError, KeyError):
+            pass
         line = {
             "metric": "whole-body-QP control ticks/s at N=4096 Mini Cheetah",
             "value": n_total * a.steps / dt, "unit": "ticks/s",
@@ -372,7 +388,7 @@ def run_rank(a):
             "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
                          "kernel": "wbc_hex_kernel<%s>" % shard["kind"].upper(),
-                         "kernel_ms": ms_per_launch, "flops_per_tick": flops,
+                         "kernel_ms": ms_per_launch, "flops_per_tick": flops, "issued": issued,
                          "kernel_ms_dist": {"median": float(np.median(each)), "p10": float(np.percentile(each, 10)),
                                             "p90": float(np.percentile(each, 90)), "launches": int(each.size),
                                             "how": "one HIP event between every two launches, after the timed region"},
