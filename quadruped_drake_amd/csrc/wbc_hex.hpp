@@ -1,6 +1,6 @@
 // wbc_hex.hpp -- one control tick computed by SIXTEEN lanes (one DPP row) per robot (product math, v4).
 //
-// Why (profiles/r01/cuts.md, profiles/r02): the quad mapping (wbc_quad.hpp) gives only N/16 wavefronts
+// Why (profiles/r01/cuts.md, profiles/r02/hex_cuts.md): round 1's 4-lanes-per-robot mapping (retired) gave only N/16 wavefronts
 // (256 at N = 4096: one SIMD of four busy per CU) and its per-lane state (three z-space columns, three
 // rows of J) does not fit 512 registers -- 1.4 KB/lane of scratch that overflows L2 once two waves
 // share a CU.  Here lane h = 4*leg + sub of a 16-lane DPP row:
@@ -211,7 +211,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   // ---- Fast path (plain friction rows only): the first trips of a tick are almost always "add the picked row with a
   // full step" on every robot of the wavefront, so the list length q is wave-uniform and equals the trip number.  With q
   // a compile-time constant the position masks, their shifts and all work on the fixed positions k < q disappear
-  // (~230 instead of ~570 instructions per trip, profiles/r02/hex_cuts.md).  The moment any robot of the wavefront
+  // (~285 instead of ~570 instructions per trip, profiles/r02/tail_experiment.md: 0.73 us per trip).  The moment any robot of the wavefront
   // needs something else (a partial step = a drop, a dependent row) the trip is abandoned BEFORE it has changed any
   // state and the generic loop below takes over.  Both paths evaluate the same expressions in the same order, so a
   // robot's result does not depend on which path its wavefront took (bit-identical; tests: batch-position invariance).
@@ -626,7 +626,7 @@ struct ParkHost {
 };
 
 // Diagnostic builds only (-DWBC_HCUT=k): return after phase k with the live values folded into the
-// outputs (see WBC_CUT_AT in wbc_quad.hpp); timed as whole kernels -> profiles/r02/hex_cuts.md.
+// outputs; timed as whole kernels (tools/build_cuts.sh, tools/run_cuts.sh) -> profiles/r02/hex_cuts.md.
 #ifdef WBC_HCUT
 #define WBC_HCUT_AT(k, expr)                                                  \
   if (WBC_HCUT == (k)) {                                                      \
