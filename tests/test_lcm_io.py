@@ -77,7 +77,7 @@ def test_wire_to_wire_tick_on_a_permuted_plant():
     the float32-rounded states the messages carry."""
     import torch
     from oracle import oracle_py as orc
-    from quadruped_drake_amd import IDController, load_model, workloads
+    from quadruped_drake_amd import IDController, workloads
     from quadruped_drake_amd.lcm_io import encode_robot_state, pack_controls, unpack_states
     _, exp = gold()
     order, act = [int(x) for x in exp["order"]], [int(x) for x in exp["act_joint"]]
