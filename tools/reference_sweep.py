@@ -23,6 +23,8 @@ from quadruped_drake_amd.planners import unpack_trunk_input  # noqa: E402
 
 LAWS = {"id": IDController, "mptc": MPTCController, "pc": PCController, "clf": CLFController}
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+dump = sys.argv[3] if len(sys.argv) > 3 else None            # .npz: inputs + what the reference's code returned (for tools/reference_sweep_gpu.py)
+dumped = {}
 backend = sys.argv[2] if len(sys.argv) > 2 else "oracle"     # "energy": the plant of tests/energy_model.py (nothing shared with oracle/)
 for kind, cfg in (("id", 2), ("id", 3), ("mptc", 3), ("mptc", 4), ("mptc", 5), ("pc", 3), ("pc", 2), ("clf", 3), ("clf", 2)):
     if backend == "energy" and cfg == 5:
@@ -32,6 +34,7 @@ for kind, cfg in (("id", 2), ("id", 3), ("mptc", 3), ("mptc", 4), ("mptc", 5), (
     ctrl = LAWS[kind](plant, 5e-3)
     p = orc.params(kind)
     rel, dvd, dmet, fails, infeasible = [], [], [], 0, 0
+    keep, taus, vds, mets = [], [], [], []
     for i in range(n):
         if b["mu"] is not None:
             ctrl.mu = float(b["mu"][i]); p.mu = float(b["mu"][i])
@@ -55,10 +58,21 @@ for kind, cfg in (("id", 2), ("id", 3), ("mptc", 3), ("mptc", 4), ("mptc", 5), (
         if st_o != 0:
             fails += 1
             continue
+        keep.append(i); taus.append(np.array(tau)); vds.append(OsqpSolver.last["x"][:18].copy()); mets.append(np.array(met))
         rel.append(np.abs(tau - tau_o).max() / max(np.abs(tau_o).max(), 1e-3))
         dvd.append(np.abs(OsqpSolver.last["x"][:18] - qp["x"][:18]).max() / (1.0 + np.abs(qp["x"][:18]).max()))
         cols = [1] if kind == "id" else [0, 1, 3]
         dmet.append(max(abs(met[c] - met_o[c]) / (1.0 + abs(met_o[c])) for c in cols))
     rel, dvd, dmet = np.array(rel), np.array(dvd), np.array(dmet)
+    if dump:
+        k = "%s_cfg%d_" % (kind, cfg)
+        keep = np.array(keep)
+        dumped.update({k + "q": b["q"][:, keep], k + "v": b["v"][:, keep], k + "targets": b["targets"][:, keep], k + "mask": b["mask"][keep],
+                       k + "mu": np.zeros(0) if b["mu"] is None else b["mu"][keep],
+                       k + "mass_scale": np.zeros(0) if b["mass_scale"] is None else b["mass_scale"][keep],
+                       k + "model": b["model"], k + "tau": np.array(taus).T, k + "vd": np.array(vds).T, k + "metrics": np.array(mets).T})
     print("%-4s cfg %d  %4d ticks: torque rel dev worst %.2e median %.2e | accelerations worst %.2e | metrics worst %.2e | "
           "not compared %d (of which infeasible for both: %d)" % (kind, cfg, rel.size, rel.max(), np.median(rel), dvd.max(), dmet.max(), fails, infeasible), flush=True)
+if dump:
+    np.savez_compressed(dump, **dumped)
+    print("dumped", dump)
