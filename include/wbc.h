@@ -233,6 +233,17 @@ int wbc_robot_states_unpack(int device, void* hip_stream, int n, int ld, const u
 int wbc_robot_controls_pack(int device, void* hip_stream, int n, int ld, const double* tau, const int* q_perm,
                             const int* act_perm, uint8_t* msgs);
 
+/* ------------------------------------------------------------------------------------------
+ * The reference's joint-space PD law (control method "B": BasicController.ControlLaw, controllers/basic_controller.py:322-352),
+ * batched and stateless: tau_v = -Kp N+(q)(q - q_nom) - Kd v, u = clip(S tau_v, -u_max, u_max).  S selects the twelve joint rows,
+ * where N+ is the identity, so u[k] = clip(-(kp (q_j - q_nom_j)) - kd v_j) with j = the plant index of the joint actuator k drives
+ * (j = q_perm[act_perm[k]]); evaluated without fused multiply-add, i.e. bit for bit what the reference's numpy computes.
+ * q[19][ld], v[18][ld], tau[12][ld] (actuator order) are device pointers; q_nom19 is a HOST array in the plant's own joint order
+ * (NULL = the reference's literal: base at (0, 0, 0.3), every leg (0, -0.8, 1.6)); the reference's gains are kp 30, kd 1.5, u_max 150.
+ * q_perm / act_perm: host int[12], NULL = identity.  Asynchronous on `hip_stream`. */
+int wbc_pd_step(int device, void* hip_stream, int n, int ld, const double* q, const double* v, const double* q_nom19,
+                double kp, double kd, double u_max, const int* q_perm, const int* act_perm, double* tau);
+
 #ifdef __cplusplus
 }
 #endif

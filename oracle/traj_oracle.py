@@ -91,3 +91,15 @@ def robot_control_message(u, order, act_joint):
     for k in range(12):
         t[order[act_joint[k]]] = u[k]
     return RS_FINGERPRINT + struct.pack(">37f", *([0.0] * 37)) + struct.pack(">12f", *t)
+
+
+def pd_control_law(q, v, q_nom=None, order=None, act_joint=None, kp=30.0, kd=1.5, u_max=150.0):
+    """controllers/basic_controller.py:322-352 for a batch: q[19, N], v[18, N] in the plant's numbering -> u[12, N] in actuator
+    order.  tau = -Kp q_err - Kd v on the joint rows (where MapQDotToVelocity is the identity), u = clip(S tau, +-u_max)."""
+    q = np.asarray(q, float); v = np.asarray(v, float)
+    qn = np.array([1.0, 0, 0, 0, 0, 0, 0.3] + [0.0, -0.8, 1.6] * 4) if q_nom is None else np.asarray(q_nom, float)
+    order = list(range(12)) if order is None else list(order)
+    act = list(range(12)) if act_joint is None else list(act_joint)
+    tau_j = -(kp * (q[7:] - qn[7:, None])) - kd * v[6:]                 # plant joint order
+    u = np.stack([tau_j[order[act[k]]] for k in range(12)])
+    return np.clip(u, -u_max, u_max)

@@ -7,4 +7,5 @@ batches of BASELINE.json's configs), stats.py (multi-GPU shard + RCCL statistics
 from .controller import IDController, MPTCController, PCController, CLFController, BatchedController, SolverError, pack_trunk_input, load_model, make_leaf_system  # noqa
 from . import workloads  # noqa
 from . import lcm_io  # noqa
+from .pd import BasicController  # noqa
 from .planners import BasicTrunkPlanner, TowrTrunkPlanner, scenario_targets, scenario_trajectory, unpack_trunk_input  # noqa

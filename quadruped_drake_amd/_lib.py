@@ -18,7 +18,7 @@ SYMBOLS = ["wbc_last_error", "wbc_version", "wbc_params_default", "wbc_create", 
            "wbc_step", "wbc_sync", "wbc_time_steps", "wbc_time_steps_result", "wbc_time_steps_each", "wbc_stats_get", "wbc_stats_reset", "wbc_set_variant", "wbc_set_vdot_output", "wbc_integrate", "wbc_rollout",
            "wbc_kernel_info", "wbc_variant_for", "wbc_trunk_state_decode", "wbc_trunk_state_to_targets", "wbc_traj_create",
            "wbc_traj_destroy", "wbc_traj_lookup", "wbc_robot_state_decode", "wbc_robot_state_encode",
-           "wbc_robot_states_unpack", "wbc_robot_controls_pack"]
+           "wbc_robot_states_unpack", "wbc_robot_controls_pack", "wbc_pd_step"]
 
 
 class WbcModel(C.Structure):
@@ -95,6 +95,8 @@ def lib():
         l.wbc_robot_states_unpack.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         l.wbc_robot_controls_pack.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                               C.c_void_p]
+        l.wbc_pd_step.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_double_p, C.c_double, C.c_double,
+                                  C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]
         for s in SYMBOLS:
             getattr(l, s)
         _lib = l

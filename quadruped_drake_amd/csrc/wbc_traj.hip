@@ -88,6 +88,22 @@ __global__ void robot_controls_pack_kernel(int n, int ld, const double* __restri
   else if (c >= 39) out = __float_as_uint((float)tau[(size_t)src.k[c - 39] * ld + i]);   // round to nearest even, like struct.pack('>f')
   w[(size_t)i * kRsWords + c] = bswap32(out);
 }
+
+// ---- BasicController.ControlLaw (controllers/basic_controller.py:322-352): joint-space PD, thread (robot i, actuator k)
+struct PdArgs { int jd[12]; double qn[12]; };   // plant joint index driven by actuator k; nominal angle of that joint
+__global__ void pd_step_kernel(int n, int ld, const double* __restrict__ q, const double* __restrict__ v, PdArgs a, double kp,
+                               double kd, double u_max, double* __restrict__ tau) {
+#pragma clang fp contract(off)   // the reference's numpy rounds each product and the difference separately: no fused multiply-add here
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+  if (i >= n) return;
+  const int j = a.jd[k];
+  const double qe = q[(size_t)(7 + j) * ld + i] - a.qn[k];
+  // -Kp@q_err - Kd@qd_err, then np.clip
+  const double p1 = kp * qe, p2 = kd * v[(size_t)(6 + j) * ld + i];
+  double u = -p1 - p2;
+  u = fmin(fmax(u, -u_max), u_max);
+  tau[(size_t)k * ld + i] = u;
+}
 }  // namespace
 
 struct wbc_traj_s {
@@ -176,6 +192,29 @@ int wbc_robot_controls_pack(int device, void* hip_stream, int n, int ld, const d
   HIP_TRY(hipSetDevice(device));
   hipLaunchKernelGGL(robot_controls_pack_kernel, dim3((n + 255) / 256, kRsWords), dim3(256), 0, (hipStream_t)hip_stream, n, ld,
                      tau, src, reinterpret_cast<uint32_t*>(msgs));
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int wbc_pd_step(int device, void* hip_stream, int n, int ld, const double* q, const double* v, const double* q_nom19,
+                double kp, double kd, double u_max, const int* q_perm, const int* act_perm, double* tau) {
+  if (n < 0 || ld < n || (n > 0 && (!q || !v || !tau))) return tmisuse("wbc_pd_step: bad argument");
+  if (!(u_max >= 0.0)) return tmisuse("wbc_pd_step: u_max must be non-negative");
+  static const double kNominal[3] = {0.0, -0.8, 1.6};   // basic_controller.py:333-340
+  PdArgs a;
+  bool seen[12] = {false};
+  for (int k = 0; k < 12; k++) {
+    const int j = act_perm ? act_perm[k] : k;
+    if (j < 0 || j >= 12) return tmisuse("wbc_pd_step: act_perm must be a permutation of 0..11");
+    const int jd = q_perm ? q_perm[j] : j;
+    if (jd < 0 || jd >= 12 || seen[jd]) return tmisuse("wbc_pd_step: q_perm / act_perm must be permutations of 0..11");
+    seen[jd] = true;
+    a.jd[k] = jd;
+    a.qn[k] = q_nom19 ? q_nom19[7 + jd] : kNominal[jd % 3];
+  }
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(device));
+  hipLaunchKernelGGL(pd_step_kernel, dim3((n + 255) / 256, 12), dim3(256), 0, (hipStream_t)hip_stream, n, ld, q, v, a, kp, kd, u_max, tau);
   HIP_TRY(hipGetLastError());
   return 0;
 }

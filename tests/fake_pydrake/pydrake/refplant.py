@@ -171,6 +171,19 @@ class RefPlant:
         qd[7:] = v[6:]          # joint rates keep their own (plant) numbering: position 7 + k <-> velocity 6 + k
         return qd
 
+    def MapQDotToVelocity(self, ctx, qdot):
+        """v = N+(q) qdot: (0, w) = 2 quat' * conj(quat) for the world-frame angular velocity (the inverse of the map above);
+        position and joint rates pass through.  The PD law feeds it q - q_nom (basic_controller.py:343)."""
+        w, x, y, z = ctx.q[:4]
+        qd = np.asarray(qdot, dtype=float)
+        a, b = qd[0], qd[1:4]
+        vec = np.array([x, y, z])
+        v = np.zeros(18)
+        v[:3] = 2.0 * (-a * vec + w * b - np.cross(b, vec))
+        v[3:6] = qd[4:7]
+        v[6:] = qd[7:]
+        return v
+
     # -- dynamics
     def CalcMassMatrixViaInverseDynamics(self, ctx):
         M = np.empty((18, 18)); M[np.ix_(self.pv, self.pv)] = self._dyn(ctx.q, ctx.v)[0]

@@ -38,7 +38,7 @@ np.object = object                                # helpers.py:19 uses the alias
 sys.path.insert(0, "/root/reference")
 import pydrake.all as fake                         # noqa: E402
 from pydrake.mathprog import OsqpSolver            # noqa: E402
-from controllers import IDController, MPTCController, PCController, CLFController   # noqa: E402  (reference code)
+from controllers import BasicController, IDController, MPTCController, PCController, CLFController   # noqa: E402  (reference code)
 from oracle import oracle_py as orc                # noqa: E402  (rigid-body terms of the stand-in plant)
 
 LAWS = {"id": IDController, "mptc": MPTCController, "pc": PCController, "clf": CLFController}
@@ -194,6 +194,29 @@ for kind, dt, t_start in (("id", 5e-3, 0.85), ("mptc", 1e-3, 0.97)):
     gold[pn + "_q"] = np.array(Q).T; gold[pn + "_v"] = np.array(V).T; gold[pn + "_tau"] = np.array(TAU).T
     print("%-22s %d ticks from t = %.3f, dt = %g: RF foot contact %s -> %s, |v|max %.3f" %
           (pn, steps, t_start, dt, True, bool(d["contact_states"][1]), np.abs(np.array(V)).max()))
+
+# the joint-space PD law (control method "B", BasicController.ControlLaw): random states, some far enough from the nominal
+# pose for the +-150 clip, on the identity plant and on the permuted one
+z = np.load(os.path.join(HERE, "cfg2_id.npz"))
+rng_pd = np.random.default_rng(31)
+qpd, vpd = z["q"][:, :24].copy(), z["v"][:, :24].copy()
+qpd[7:, 12:] += rng_pd.uniform(-8.0, 8.0, (12, 12)); vpd[6:, 18:] *= 40.0
+for pn, order, act in (("pd_identity", None, None), ("pd_perm", ORDER, ACT)):
+    plant = fake.RefPlant("mini_cheetah", body_frame="body", order=order, act_joint=act)
+    ctrl = BasicController(plant, 5e-3)
+    U = np.zeros((12, qpd.shape[1]))
+    for i in range(qpd.shape[1]):
+        qd, vd_ = qpd[:, i].copy(), vpd[:, i].copy()
+        if order is not None:
+            for j in range(12):
+                qd[7 + order[j]] = qpd[7 + j, i]; vd_[6 + order[j]] = vpd[6 + j, i]
+        ctx = ctrl.CreateDefaultContext()
+        ctrl.get_input_port(0).FixValue(ctx, np.concatenate([qd, vd_]))
+        U[:, i] = ctrl.get_output_port(0).Eval(ctx)
+    gold[pn + "_q"], gold[pn + "_v"], gold[pn + "_u"] = qpd, vpd, U
+    gold[pn + "_order"] = np.arange(12) if order is None else np.array(order)
+    gold[pn + "_act_joint"] = np.arange(12) if act is None else np.array(act)
+    print("%-22s PD law, %d ticks, clipped entries: %d" % (pn, U.shape[1], int((np.abs(U) == 150.0).sum())))
 
 # NOTHING SHARED: the same reference code over a plant whose rigid-body terms come from tests/energy_model.py (plain FK +
 # Kane projection, numerically differentiated twists) instead of oracle/ -- reference law code + independent dynamics +
