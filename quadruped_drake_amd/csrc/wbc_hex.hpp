@@ -218,7 +218,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #ifndef WBC_QF_ID
 #define WBC_QF_ID 8
 #endif
-  constexpr int QF = (!PC && !TB && NV == NZ) ? (GAIN ? 8 : WBC_QF_ID) : 0;   // ID stands add up to 8-12 rows before the first drop
+  constexpr int QF = (!TB && NV == NZ) ? (GAIN ? 8 : WBC_QF_ID) : 0;   // ID stands add up to 8-12 rows before the first drop; PC: see pcv below
   bool generic = true;   // wave-uniform: the generic loop still has work to do
   if constexpr (QF > 0) {
     bool stop = false;   // wave-uniform
@@ -241,15 +241,20 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         key = qo.min16(key);
         pf = (key < 1e299) ? hex_key_index(key) : -1;
       }
+      // PC law: the dense row (Vdot <= 0) is never added here -- a robot whose dense row is violated sends the wavefront to the
+      // generic loop (rare: ~5 % of the robots); while it is inactive the fast trips only carry its image and value along
+      const bool pcv = PC && pc && spc < -tol;
       // every wavefront's last trip finds nothing left to repair anywhere: leave before the crossbar round trip
-      if (qo.wave_all(done || pf < 0)) { done = true; stop = true; generic = false; return; }
+      if (qo.wave_all(done || (pf < 0 && !pcv))) { done = true; stop = true; generic = false; return; }
       // ONE round trip: the picked row's image, value and norm from its lane (own lane when there is no candidate)
       const int pl = (pf >= 0) ? pf : h;
       double d[NZ];
 #pragma unroll
       for (int k = 0; k < NZ; k++) d[k] = qo.bcast16d(Dh[k], pl);
       const double spx = qo.bcast16d(sh_, pl), dnx = qo.bcast16d(dnh, pl);
-      if (!(pf >= 0 && spx < -tol)) done = true;        // nothing (left) to repair on this robot
+      // the dense row wins the pick when it is the most violated one (generic loop: spc < sp)
+      const bool pcpick = pcv && !(pf >= 0 && !(spc < spx));
+      if (!(pf >= 0 && spx < -tol) && !pcpick) done = true;        // nothing (left) to repair on this robot
       if (qo.wave_all(done)) { stop = true; generic = false; return; }
       double d2n = 0.0, zd = 0.0, sd = 0.0, r_h = 0.0;
       static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; d2n = fmad(d[k], d[k], d2n); });
@@ -267,7 +272,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       const bool dependent = !(d2n > 1e-22 * dnx);
       const double t2 = -spx * fast_rcp(d2n);
       const bool full = !dependent && (!have_t1 || !(t1 < t2));
-      if (qo.wave_any(!done && !full) || WBC_GI_FORCE_BAIL(qc)) { stop = true; return; }   // not an add-with-full-step everywhere: generic loop, state untouched
+      if (qo.wave_any(!done && (!full || pcpick)) || WBC_GI_FORCE_BAIL(qc)) { stop = true; return; }   // not a friction add-with-full-step everywhere: generic loop, state untouched
       if (!done) {
         iters++;
         WBC_GI_STAT(if (h == 0) g_gi_fast_trips++);
@@ -285,6 +290,14 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         Jr[qc] = fmad(-w, vq, Jr[qc]);
         Dh[qc] = fmad(-wd, vq, Dh[qc]);
         static_for<NZ - qc - 1>([&](auto KK) { constexpr int k = qc + 1 + KK; Jr[k] = fmad(-w, d[k], Jr[k]); Dh[k] = fmad(-wd, d[k], Dh[k]); });
+        if (PC) {
+          double sdpc = 0.0;
+          static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; sdpc = fmad(Dpc[k], d[k], sdpc); });
+          spc = fmad(t2, sdpc, spc);
+          const double wp = fmad(-alpha, Dpc[qc], sdpc) * beta;
+          Dpc[qc] = fmad(-wp, vq, Dpc[qc]);
+          static_for<NZ - qc - 1>([&](auto KK) { constexpr int k = qc + 1 + KK; Dpc[k] = fmad(-wp, d[k], Dpc[k]); });
+        }
         const bool mine = (h == pf);
         Wr[qc] = mine ? ia : -r_h * ia;
         u_h = mine ? t2 : u_h;
@@ -369,7 +382,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     for (int k = 0; k < NV; k++) {
       zd = fmad(Jr[k], dm[k], zd);
       sd = fmad(Dh[k], dm[k], sd);
-      if (PC) sdpc += Dpc[k] * dm[k];
+      if (PC) sdpc = fmad(Dpc[k], dm[k], sdpc);
       if (TB) sdt += Dt[k] * dm[k];
     }
     // dual step direction r = R^-1 d[0:q]: every active row's lane holds its row of W = R^-1
@@ -418,7 +431,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       const double tz = dependent ? 0.0 : t;
       z = fmad(tz, zd, z);
       sh_ = fmad(tz, sd, sh_);
-      if (PC) spc += tz * sdpc;
+      if (PC) spc = fmad(tz, sdpc, spc);
       if (TB) yt += tz * sdt;
       sp += tz * d2n;
     }
@@ -441,16 +454,16 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         hv[k] = fmad(-alpha, eq[k], dm[k]);   // entry q: dq - alpha = vq
         jq = fmad(eq[k], Jr[k], jq);
         dhq = fmad(eq[k], Dh[k], dhq);
-        if (PC) dpq += eq[k] * Dpc[k];
+        if (PC) dpq = fmad(eq[k], Dpc[k], dpq);
         if (TB) dtq += eq[k] * Dt[k];
       }
       const double w = fmad(-alpha, jq, zd) * beta, wd = fmad(-alpha, dhq, sd) * beta;
-      const double wp = PC ? (sdpc - alpha * dpq) * beta : 0.0, wt = TB ? (sdt - alpha * dtq) * beta : 0.0;
+      const double wp = PC ? fmad(-alpha, dpq, sdpc) * beta : 0.0, wt = TB ? (sdt - alpha * dtq) * beta : 0.0;
 #pragma unroll
       for (int k = 0; k < NV; k++) {
         Jr[k] = fmad(-w, hv[k], Jr[k]);
         Dh[k] = fmad(-wd, hv[k], Dh[k]);
-        if (PC) Dpc[k] -= wp * hv[k];
+        if (PC) Dpc[k] = fmad(-wp, hv[k], Dpc[k]);
         if (TB) Dt[k] -= wt * hv[k];
       }
       // W' = [W, -r/alpha; 0, 1/alpha]  (rows of inactive lanes are zero, r_h = 0 there)

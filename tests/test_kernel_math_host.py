@@ -172,7 +172,7 @@ def test_fast_and_generic_paths_round_identically():
     (what a wave-mate's drop causes) must give the same bits.  Host instantiation; the device A/B is tools/dump_tau.py
     on -DWBC_DEV_FORCE_BAIL=k builds (bit-identical)."""
     L = ht.lib()
-    for cfg, kind in ((2, "id"), (3, "mptc"), (3, "id")):
+    for cfg, kind in ((2, "id"), (3, "mptc"), (3, "id"), (3, "pc"), (2, "pc")):
         b = workloads.make_batch(cfg, n=32)
         t = orc.load_model_json(b["model"])
         L.host_gi_force_bail(-1)
