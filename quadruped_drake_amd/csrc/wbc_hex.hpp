@@ -31,6 +31,7 @@
 // host-only diagnostics (tools/host_tick.cpp): how many fast / generic active-set trips a robot ran
 #if !defined(__HIPCC__) && defined(WBC_HOST_GI_STATS)
 extern int g_gi_fast_trips, g_gi_generic_trips, g_gi_drops, g_gi_force_bail;
+extern double* g_gi_dump;   // analysis: [16][NV + 3] per robot = the active set's inputs (own row of J, z, mu_n, inv_s) of every lane
 #define WBC_GI_FORCE_BAIL(qc) (g_gi_force_bail == (qc))
 #define WBC_GI_STAT(x) do { x; } while (0)
 #else
@@ -111,6 +112,8 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
 // not depend on which path its wavefront took), so nothing there is left to the compiler's contraction choices.
 WBC_HD double fmad(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+WBC_HD double mk2(double e) { return 1.0 - e; }   // complement of a one-hot mask entry
+
 // 16-lane argmin as ONE fmin butterfly: the 5-bit candidate index rides in the low mantissa bits of the value
 // (a 2^-47 relative perturbation of the returned minimum; "no candidate" is the finite HEX_NONE, never inf, so
 // that the packed key is never a NaN).  4 x (2 DPP moves + v_min_f64) instead of 4 x ~12 compare/select steps.
@@ -157,6 +160,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
                   double t0n = 0.0, double bt = -1.0) {
   const int sb = h & 3;
   const bool pc = PC && pc_inv > 0.0;
+  WBC_GI_STAT(if (g_gi_dump) { double* o = g_gi_dump + h * 16; for (int k = 0; k < NV && k < 13; k++) o[k] = Jr[k]; o[13] = z; o[14] = mu_n; o[15] = ct ? inv_s : 0.0; });
   const double sg = (sb & 1) ? inv_s : -inv_s;   // own row: n_h = sg * e_(leg, sb>>1) + mu_n * e_(leg, 2)
   double Dh[NV], sh_, dnh = 0.0;
 #pragma unroll
@@ -165,20 +169,20 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     dnh += Dh[k] * Dh[k];
   }
   sh_ = sg * qo.leg_pairs(z) + mu_n * qo.leg_bcast(z, 2);
+  const double npl = PC ? -vrow_own * pc_inv : 0.0;   // own entry of the dense row's normal
   double Dpc[NV], spc = 0.0, dnpc = 0.0, u_pc = 0.0;
-  int pos_pc = -1;
+  bool act_pc = false;
   if (PC) {
-    const double npl = -vrow_own * pc_inv;
 #pragma unroll
     for (int k = 0; k < NV; k++) { Dpc[k] = qo.sum16(Jr[k] * npl); dnpc += Dpc[k] * Dpc[k]; }
     spc = -(qo.sum16(vrow_own * z) + vc) * pc_inv;
   }
   double u_h = 0.0, Wr[NV], Wpc[NV];
-  int pos_h = -1;
+  bool act_h = false;   // own friction row is in the active set
 #pragma unroll
   for (int k = 0; k < NV; k++) { Wr[k] = 0.0; Wpc[k] = 0.0; }
   double Dt[NV], Wt[NV], yt = 0.0, dnt = 0.0, u_t = 0.0, sig_t = 1.0;
-  int pos_t = -1;
+  bool act_t = false;
   const bool elig_t = TB && bt >= 0.0;
   if (TB) {
 #pragma unroll
@@ -195,12 +199,6 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     for (int k = 0; k < NV; k++) dnt += Dt[k] * Dt[k];
   }
   int q = 0, iters = 0, status = ST_OK;
-  unsigned long long active = 0ull;
-  // position masks kept as doubles (replicated): eq = one-hot of the next free position q, mk = 1 on the free
-  // positions k >= q.  Products with them replace three select chains per trip (d masked, d[q], the reflector).
-  double eq[NV], mk[NV];
-#pragma unroll
-  for (int k = 0; k < NV; k++) { eq[k] = (k == 0) ? 1.0 : 0.0; mk[k] = 1.0; }
   const int maxit = 200;
   bool done = false, need_pick = true, picked = false;
   int p = -1;
@@ -210,11 +208,11 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   const double tol = 1e-13 * (1.0 + qo.max16(fabs(z)));
   // ---- Fast path (plain friction rows only): the first trips of a tick are almost always "add the picked row with a
   // full step" on every robot of the wavefront, so the list length q is wave-uniform and equals the trip number.  With q
-  // a compile-time constant the position masks, their shifts and all work on the fixed positions k < q disappear
-  // (~285 instead of ~570 instructions per trip, profiles/r02/tail_experiment.md: 0.73 us per trip).  The moment any robot of the wavefront
-  // needs something else (a partial step = a drop, a dependent row) the trip is abandoned BEFORE it has changed any
-  // state and the generic loop below takes over.  Both paths evaluate the same expressions in the same order, so a
-  // robot's result does not depend on which path its wavefront took (bit-identical; tests: batch-position invariance).
+  // a compile-time constant the position masks and all work on the fixed positions k < q disappear.  The moment any
+  // robot of the wavefront needs something else (a partial step = a drop, a dependent row) the trip is abandoned BEFORE
+  // it has changed any state and the generic loop below takes over.  Both paths evaluate the same expressions in the
+  // same order, so a robot's result does not depend on which path its wavefront took (bit-identical; tests:
+  // batch-position invariance).
 #ifndef WBC_QF_ID
 #define WBC_QF_ID 8
 #endif
@@ -229,7 +227,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       int pf;
       {
         double key = HEX_NONE;
-        if (!done && ct && !((active >> h) & 1ull)) {
+        if (!done && ct && !act_h) {
           if (GAIN) {
             double dd2 = 0.0;
             static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; dd2 = fmad(Dh[k], Dh[k], dd2); });
@@ -260,11 +258,11 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; d2n = fmad(d[k], d[k], d2n); });
       static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; zd = fmad(Jr[k], d[k], zd); sd = fmad(Dh[k], d[k], sd); });
       static_for<qc>([&](auto KK) { r_h = fmad(Wr[KK], d[KK], r_h); });
-      r_h = (pos_h >= 0) ? r_h : 0.0;
+      r_h = act_h ? r_h : 0.0;
       double t1 = INF;
       bool have_t1 = false;
       if (qc > 0) {
-        double key = (pos_h >= 0 && r_h > 0.0) ? hex_pack_key(u_h * fast_rcp(r_h), h) : HEX_NONE;
+        double key = (act_h && r_h > 0.0) ? hex_pack_key(u_h * fast_rcp(r_h), h) : HEX_NONE;
         key = qo.min16(key);
         have_t1 = key < 1e299;
         t1 = have_t1 ? key : INF;
@@ -301,15 +299,24 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         const bool mine = (h == pf);
         Wr[qc] = mine ? ia : -r_h * ia;
         u_h = mine ? t2 : u_h;
-        pos_h = mine ? qc : pos_h;
-        active |= (1ull << pf);
+        act_h = act_h || mine;
         q = qc + 1;
       }
     });
   }
+  // ---- Generic loop.  Position mask kept as doubles (replicated): mk = 1 on the free slots k >= q; the one-hot of the next free
+  // slot is eq[k] = mk[k] - mk[k-1].  Products with them replace select chains (d masked, d[q], the reflector).
+  // Every trip is ONE Householder reflection per robot, whatever the robot does:
+  //   append (full step):   x = d[q:]                      -> alpha e_q,     then q + 1
+  //   drop (partial step):  x = W row of the blocking row  -> alpha e_(q-1), then q - 1.
+  // The drop: that row of W = R^-1 is, within the used slots, the normal of the span of the REMAINING active images
+  // (W R = I), so the reflection leaves every remaining image with a zero in slot q-1: the slot is free again, the list
+  // stays a prefix, and there is no position bookkeeping and no per-position Givens sweep (round 2: up to 11 predicated
+  // rotations with two 16-lane sums each; the divergent add / drop branches cost a lock-step trip both bodies).
+  double mk[NV];
   if (generic) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) { eq[k] = (k == q) ? 1.0 : 0.0; mk[k] = (k >= q) ? 1.0 : 0.0; }
+    for (int k = 0; k < NV; k++) mk[k] = (k >= q) ? 1.0 : 0.0;
   }
   for (int trip = 0; generic && trip < maxit; trip++) {
     if (!done && need_pick) {
@@ -324,14 +331,14 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
           for (int k = 0; k < NV; k++) dd2 = fmad(mk[k] * Dh[k], Dh[k], dd2);
           // a violated row whose image has no free part (linearly dependent on the active ones) must still be
           // picked -- the dependent-step logic below resolves or reports it -- so it gets the largest finite gain
-          if (ct && !((active >> h) & 1ull) && sh_ < -tol)
+          if (ct && !act_h && sh_ < -tol)
             key = hex_pack_key((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
         } else {
-          if (ct && !((active >> h) & 1ull)) key = hex_pack_key(sh_, h);
+          if (ct && !act_h) key = hex_pack_key(sh_, h);
         }
         if (TB) {
           const double st_ = bt - fabs(yt);
-          if (elig_t && !((active >> (32 + h)) & 1ull) && st_ < key) key = hex_pack_key(st_, 16 + h);
+          if (elig_t && !act_t && st_ < key) key = hex_pack_key(st_, 16 + h);
         }
         key = qo.min16(key);
         const int ix = hex_key_index(key);
@@ -354,7 +361,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     if (picked) {
       picked = false;
       if (p >= 0 && p < 16) sp = sp_x;
-      if (pc && !((active >> 16) & 1ull) && spc < sp) { sp = spc; p = 16; }
+      if (pc && !act_pc && spc < sp) { sp = spc; p = 16; }
       if (!(sp < -tol)) p = -1;
       if (p < 0) {
         done = true;
@@ -367,9 +374,10 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       }
     }
     if (qo.wave_all(done)) break;
-    if (done) continue;
-    iters++;
-    WBC_GI_STAT(if (h == 0) g_gi_generic_trips++);
+    // from here on the trip is straight-line code: a finished robot runs along with a zero step and a null reflection
+    const bool live = !done;
+    if (live) iters++;
+    WBC_GI_STAT(if (h == 0 && live) g_gi_generic_trips++);
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       if (TB) d[k] = sgp * d[k];
@@ -383,7 +391,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       zd = fmad(Jr[k], dm[k], zd);
       sd = fmad(Dh[k], dm[k], sd);
       if (PC) sdpc = fmad(Dpc[k], dm[k], sdpc);
-      if (TB) sdt += Dt[k] * dm[k];
+      if (TB) sdt = fmad(Dt[k], dm[k], sdt);
     }
     // dual step direction r = R^-1 d[0:q]: every active row's lane holds its row of W = R^-1
     // (slots k >= q of every W row are zero by construction, so d needs no masking here)
@@ -391,20 +399,19 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       r_h = fmad(Wr[k], d[k], r_h);
-      if (PC) r_pc += Wpc[k] * d[k];
-      if (TB) r_t += Wt[k] * d[k];
+      if (PC) r_pc = fmad(Wpc[k], d[k], r_pc);
+      if (TB) r_t = fmad(Wt[k], d[k], r_t);
     }
-    r_h = (pos_h >= 0) ? r_h : 0.0;
-    if (PC) r_pc = (pos_pc >= 0) ? r_pc : 0.0;
-    if (TB) r_t = (pos_t >= 0) ? r_t : 0.0;
-    // blocking multiplier: min over active rows with r > 0 of u / r (nothing to do while no row is active
-    // anywhere in the wavefront -- every robot's first trip)
+    r_h = act_h ? r_h : 0.0;
+    if (PC) r_pc = act_pc ? r_pc : 0.0;
+    if (TB) r_t = act_t ? r_t : 0.0;
+    // blocking multiplier: min over active rows with r > 0 of u / r
     double t1 = INF;
     int hd = -1;
-    if (qo.wave_max_int(q) > 0) {
-      double key = (pos_h >= 0 && r_h > 0.0) ? hex_pack_key(u_h * fast_rcp(r_h), h) : HEX_NONE;
+    {
+      double key = (act_h && r_h > 0.0) ? hex_pack_key(u_h * fast_rcp(r_h), h) : HEX_NONE;
       if (TB) {
-        const double c = (pos_t >= 0 && r_t > 0.0) ? u_t * fast_rcp(r_t) : HEX_NONE;
+        const double c = (act_t && r_t > 0.0) ? u_t * fast_rcp(r_t) : HEX_NONE;
         if (c < key) key = hex_pack_key(c, 16 + h);
       }
       key = qo.min16(key);
@@ -413,171 +420,149 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       t1 = any ? key : INF;
       hd = any ? ((ix < 16) ? ix : 16 + ix) : -1;
       if (PC) {
-        const double c = (pos_pc >= 0 && r_pc > 0.0) ? u_pc * fast_rcp(r_pc) : INF;
+        const double c = (act_pc && r_pc > 0.0) ? u_pc * fast_rcp(r_pc) : INF;
         if (c < t1) { t1 = c; hd = 16; }
       }
     }
     const bool have_t1 = hd >= 0;
     const bool dependent = !(d2n > 1e-22 * dnp) || q == NV;
     const double t2 = -sp * fast_rcp(d2n);   // n_p' J2 J2' n_p = |d[q:]|^2
-    if (dependent && !have_t1) { status = ST_SINGULAR; done = true; continue; }
-    const bool full = !dependent && (!have_t1 || !(t1 < t2));
-    const double t = full ? t2 : t1;
+    if (live && dependent && !have_t1) { status = ST_SINGULAR; done = true; }
+    const bool go = !done;
+    const bool full = go && !dependent && (!have_t1 || !(t1 < t2));
+    const bool drop = go && !full;
+    const double t = full ? t2 : (drop ? t1 : 0.0);
     u_h = fmad(-t, r_h, u_h);
-    if (PC) u_pc -= t * r_pc;
-    if (TB) u_t -= t * r_t;
+    if (PC) u_pc = fmad(-t, r_pc, u_pc);
+    if (TB) u_t = fmad(-t, r_t, u_t);
     up += t;
     {
-      const double tz = dependent ? 0.0 : t;
+      const double tz = (dependent || !go) ? 0.0 : t;
       z = fmad(tz, zd, z);
       sh_ = fmad(tz, sd, sh_);
       if (PC) spc = fmad(tz, sdpc, spc);
-      if (TB) yt += tz * sdt;
-      sp += tz * d2n;
+      if (TB) yt = fmad(tz, sdt, yt);
+      sp = go ? fmad(tz, d2n, sp) : sp;
     }
-    if (full) {
-      // one Householder reflection H on d[q:] (H d2 = alpha e_q);  J2 <- J2 H on the own row, images alike
-      double dq = 0.0, dq1 = 0.0;
+    // ---- the trip's reflection: x onto slot q (append) or, after q - 1, onto the freed slot (drop)
+    double x[NV], n2 = d2n, c_j = zd, c_d = sd, c_p = sdpc, c_t = sdt, c_w = 0.0, c_wp = 0.0, c_wt = 0.0;
 #pragma unroll
-      for (int k = 0; k < NV; k += 2) { dq += eq[k] * d[k]; if (k + 1 < NV) dq1 += eq[k + 1] * d[k + 1]; }
-      dq += dq1;
-      const double nrm = fast_sqrt(d2n);
-      const double alpha = (dq > 0.0) ? -nrm : nrm;
-      const double vq = dq - alpha;
-      const double ia = fast_rcp(alpha);
-      const double beta = fast_rcp(nrm * (nrm + fabs(dq)));   // 2 / (v'v)
-      // x . v = x . d[q:] - alpha x_q (the dots with d[q:] are zd, sd ... already; x_q picked by the one-hot mask)
-      double jq = 0.0, dhq = 0.0, dpq = 0.0, dtq = 0.0;
-      double hv[NV];
+    for (int k = 0; k < NV; k++) x[k] = dm[k];
+    const bool anyd = qo.wave_any(drop);
+    if (anyd) {
+      WBC_GI_STAT(if (h == 0 && drop) g_gi_drops++);
+      double w[NV];
 #pragma unroll
-      for (int k = 0; k < NV; k++) {
-        hv[k] = fmad(-alpha, eq[k], dm[k]);   // entry q: dq - alpha = vq
-        jq = fmad(eq[k], Jr[k], jq);
-        dhq = fmad(eq[k], Dh[k], dhq);
-        if (PC) dpq = fmad(eq[k], Dpc[k], dpq);
-        if (TB) dtq += eq[k] * Dt[k];
-      }
-      const double w = fmad(-alpha, jq, zd) * beta, wd = fmad(-alpha, dhq, sd) * beta;
-      const double wp = PC ? fmad(-alpha, dpq, sdpc) * beta : 0.0, wt = TB ? (sdt - alpha * dtq) * beta : 0.0;
-#pragma unroll
-      for (int k = 0; k < NV; k++) {
-        Jr[k] = fmad(-w, hv[k], Jr[k]);
-        Dh[k] = fmad(-wd, hv[k], Dh[k]);
-        if (PC) Dpc[k] = fmad(-wp, hv[k], Dpc[k]);
-        if (TB) Dt[k] -= wt * hv[k];
-      }
-      // W' = [W, -r/alpha; 0, 1/alpha]  (rows of inactive lanes are zero, r_h = 0 there)
-      const bool mine = (h == p);
-      {
-        const double wq = mine ? ia : -r_h * ia;
-#pragma unroll
-        for (int k = 0; k < NV; k++) Wr[k] = fmad(eq[k], wq, Wr[k]);   // slot q is zero beforehand
-      }
-      u_h = mine ? up : u_h;
-      pos_h = mine ? q : pos_h;
-      if (TB) {
-        const bool tm = (p == 32 + h);
-        const double wq = tm ? ia : -r_t * ia;
-#pragma unroll
-        for (int k = 0; k < NV; k++) Wt[k] += eq[k] * wq;
-        u_t = tm ? up : u_t; pos_t = tm ? q : pos_t; sig_t = tm ? sgp : sig_t;
-      }
+      for (int k = 0; k < NV; k++) w[k] = qo.bcast16d((TB && hd >= 32) ? Wt[k] : Wr[k], hd & 15);
       if (PC) {
-        const bool pm = (p == 16);
-        const double wq = pm ? ia : -r_pc * ia;
 #pragma unroll
-        for (int k = 0; k < NV; k++) Wpc[k] += eq[k] * wq;
-        u_pc = pm ? up : u_pc; pos_pc = pm ? q : pos_pc;
+        for (int k = 0; k < NV; k++) w[k] = (hd == 16) ? Wpc[k] : w[k];
       }
-      active |= (1ull << p);
-      q++;
+      // q - 1 for the dropping robots: mk gains the one-hot of slot q - 1 (= mk[k+1] - mk[k])
+      const double dl = drop ? 1.0 : 0.0;
+      if (drop) q--;
 #pragma unroll
-      for (int k = NV - 1; k >= 0; k--) {
-        mk[k] -= eq[k];
-        eq[k] = (k > 0) ? eq[k - 1] : 0.0;
+      for (int k = 0; k < NV; k++) mk[k] = fmad(dl, ((k + 1 < NV) ? mk[k + 1] : 1.0) - mk[k], mk[k]);
+      double wn = 0.0, wj = 0.0, wdh = 0.0, ww = 0.0, wp1 = 0.0, wp2 = 0.0, wt1 = 0.0, wt2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        wn = fmad(w[k], w[k], wn);
+        wj = fmad(Jr[k], w[k], wj);
+        wdh = fmad(Dh[k], w[k], wdh);
+        ww = fmad(Wr[k], w[k], ww);
+        if (PC) { wp1 = fmad(Dpc[k], w[k], wp1); wp2 = fmad(Wpc[k], w[k], wp2); }
+        if (TB) { wt1 = fmad(Dt[k], w[k], wt1); wt2 = fmad(Wt[k], w[k], wt2); }
       }
-      need_pick = true;
-      continue;
+#pragma unroll
+      for (int k = 0; k < NV; k++) x[k] = drop ? w[k] : x[k];
+      n2 = drop ? wn : n2; c_j = drop ? wj : c_j; c_d = drop ? wdh : c_d; c_w = drop ? ww : 0.0;
+      if (PC) { c_p = drop ? wp1 : c_p; c_wp = drop ? wp2 : 0.0; }
+      if (TB) { c_t = drop ? wt1 : c_t; c_wt = drop ? wt2 : 0.0; }
     }
-    // partial / pure dual step: drop the active row hd (list position ld)
-    WBC_GI_STAT(if (h == 0) g_gi_drops++);
+    double eq[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) eq[k] = (k > 0) ? mk[k] - mk[k - 1] : mk[0];
+    double xq = 0.0, xq1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k += 2) { xq += eq[k] * x[k]; if (k + 1 < NV) xq1 += eq[k + 1] * x[k + 1]; }
+    xq += xq1;
+    const double nrm = fast_sqrt(n2);
+    const double alpha = (xq > 0.0) ? -nrm : nrm;
+    const double ia = fast_rcp(alpha);
+    const double beta = (full || drop) ? fast_rcp(nrm * (nrm + fabs(xq))) : 0.0;   // 2 / (v'v); null reflection for a robot that rests
+    // y . v = y . x - alpha y_q (the dots with x are there already; y_q picked by the one-hot mask)
+    double jq = 0.0, dhq = 0.0, dpq = 0.0, dtq = 0.0;
+    double hv[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      hv[k] = fmad(-alpha, eq[k], x[k]);   // entry q: x_q - alpha
+      jq = fmad(eq[k], Jr[k], jq);
+      dhq = fmad(eq[k], Dh[k], dhq);
+      if (PC) dpq = fmad(eq[k], Dpc[k], dpq);
+      if (TB) dtq = fmad(eq[k], Dt[k], dtq);
+    }
+    const double wj_ = fmad(-alpha, jq, c_j) * beta, wd = fmad(-alpha, dhq, c_d) * beta;
+    const double wp = PC ? fmad(-alpha, dpq, c_p) * beta : 0.0, wt = TB ? fmad(-alpha, dtq, c_t) * beta : 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      Jr[k] = fmad(-wj_, hv[k], Jr[k]);
+      Dh[k] = fmad(-wd, hv[k], Dh[k]);
+      if (PC) Dpc[k] = fmad(-wp, hv[k], Dpc[k]);
+      if (TB) Dt[k] = fmad(-wt, hv[k], Dt[k]);
+    }
+    if (anyd) {
+      // W' = W H on the rows; the freed slot is zero again in every W row (appends add into it: an appending robot's slot q
+      // is still zero here, so clearing it is harmless), the dropped row's own W row is cleared
+      double wrq = 0.0, wpq = 0.0, wtq = 0.0;
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        wrq = fmad(eq[k], Wr[k], wrq);
+        if (PC) wpq = fmad(eq[k], Wpc[k], wpq);
+        if (TB) wtq = fmad(eq[k], Wt[k], wtq);
+      }
+      const double cw = fmad(-alpha, wrq, c_w) * beta;
+      const double cwp = PC ? fmad(-alpha, wpq, c_wp) * beta : 0.0, cwt = TB ? fmad(-alpha, wtq, c_wt) * beta : 0.0;
+      const bool mined = drop && (h == hd), tmd = TB && drop && (hd == 32 + h), pmd = PC && drop && (hd == 16);
+      const double keep = mined ? 0.0 : 1.0, keept = tmd ? 0.0 : 1.0, keepp = pmd ? 0.0 : 1.0;
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        double a = fmad(-cw, hv[k], Wr[k]);
+        a = fmad(-eq[k], a, a);
+        Wr[k] = a * keep;
+        if (PC) { double b = fmad(-cwp, hv[k], Wpc[k]); b = fmad(-eq[k], b, b); Wpc[k] = b * keepp; }
+        if (TB) { double b = fmad(-cwt, hv[k], Wt[k]); b = fmad(-eq[k], b, b); Wt[k] = b * keept; }
+      }
+      u_h = mined ? 0.0 : u_h;
+      act_h = act_h && !mined;
+      if (TB) { u_t = tmd ? 0.0 : u_t; act_t = act_t && !tmd; }
+      if (PC) { u_pc = pmd ? 0.0 : u_pc; act_pc = act_pc && !pmd; }
+    }
+    // append: W' = [W, -r/alpha; 0, 1/alpha]  (rows of inactive lanes are zero, r_h = 0 there; slot q is zero beforehand)
     {
-      int ld = qo.bcast16d_i((TB && hd >= 32) ? pos_t : pos_h, hd & 15);
-      if (PC) ld = (hd == 16) ? pos_pc : ld;
-      active &= ~(1ull << hd);
-      {
-        const bool mine = (h == hd);
-        u_h = mine ? 0.0 : u_h;
-        pos_h = mine ? -1 : ((pos_h > ld) ? pos_h - 1 : pos_h);
+      const bool mine = full && (h == p);
+      const double wq = full ? (mine ? ia : -r_h * ia) : 0.0;
 #pragma unroll
-        for (int k = 0; k < NV; k++) Wr[k] = mine ? 0.0 : Wr[k];
-      }
+      for (int k = 0; k < NV; k++) Wr[k] = fmad(eq[k], wq, Wr[k]);
+      u_h = mine ? up : u_h;
+      act_h = act_h || mine;
       if (TB) {
-        const bool tm = (hd == 32 + h);
-        u_t = tm ? 0.0 : u_t;
-        pos_t = tm ? -1 : ((pos_t > ld) ? pos_t - 1 : pos_t);
+        const bool tm = full && (p == 32 + h);
+        const double wqt = full ? (tm ? ia : -r_t * ia) : 0.0;
 #pragma unroll
-        for (int k = 0; k < NV; k++) Wt[k] = tm ? 0.0 : Wt[k];
+        for (int k = 0; k < NV; k++) Wt[k] = fmad(eq[k], wqt, Wt[k]);
+        u_t = tm ? up : u_t; act_t = act_t || tm; sig_t = tm ? sgp : sig_t;
       }
       if (PC) {
-        const bool pm = (hd == 16);
-        u_pc = pm ? 0.0 : u_pc;
-        pos_pc = pm ? -1 : ((pos_pc > ld) ? pos_pc - 1 : pos_pc);
+        const bool pm = full && (p == 16);
+        const double wqp = full ? (pm ? ia : -r_pc * ia) : 0.0;
 #pragma unroll
-        for (int k = 0; k < NV; k++) Wpc[k] = pm ? 0.0 : Wpc[k];
+        for (int k = 0; k < NV; k++) Wpc[k] = fmad(eq[k], wqp, Wpc[k]);
+        u_pc = pm ? up : u_pc; act_pc = act_pc || pm;
       }
-      q--;
-      // columns ld..q-1 now carry one sub-diagonal entry each: rotate rows (j, j+1), j = ld..q-1
+      const double fl = full ? 1.0 : 0.0;
+      if (full) { q++; need_pick = true; }
 #pragma unroll
-      for (int j = 0; j < NV - 1; j++) {
-        if (j >= ld && j < q) {
-          // (a, b) = entries (j, j+1) of the column now at position j: the image of the row whose position is j
-          const bool here = (pos_h == j), here_t = TB && (pos_t == j);
-          double a = qo.sum16(here ? Dh[j] : (here_t ? sig_t * Dt[j] : 0.0)),
-                 b = qo.sum16(here ? Dh[j + 1] : (here_t ? sig_t * Dt[j + 1] : 0.0));
-          if (PC) { a = (pos_pc == j) ? Dpc[j] : a; b = (pos_pc == j) ? Dpc[j + 1] : b; }
-          const double ih = fast_rcp(fast_sqrt(a * a + b * b));
-          const double c = a * ih, sn = b * ih;
-          {
-            const double x = Wr[j], y = Wr[j + 1];
-            Wr[j] = c * x + sn * y;
-            Wr[j + 1] = c * y - sn * x;
-          }
-          if (PC) {
-            const double x = Wpc[j], y = Wpc[j + 1];
-            Wpc[j] = c * x + sn * y;
-            Wpc[j + 1] = c * y - sn * x;
-          }
-          if (TB) {
-            { const double x = Wt[j], y = Wt[j + 1]; Wt[j] = c * x + sn * y; Wt[j + 1] = c * y - sn * x; }
-            { const double x = Dt[j], y = Dt[j + 1]; Dt[j] = c * x + sn * y; Dt[j + 1] = c * y - sn * x; }
-          }
-          {
-            const double x = Jr[j], y = Jr[j + 1];
-            Jr[j] = c * x + sn * y;
-            Jr[j + 1] = c * y - sn * x;
-          }
-          {
-            const double x = Dh[j], y = Dh[j + 1];
-            Dh[j] = c * x + sn * y;
-            Dh[j + 1] = c * y - sn * x;
-          }
-          if (PC) {
-            const double x = Dpc[j], y = Dpc[j + 1];
-            Dpc[j] = c * x + sn * y;
-            Dpc[j + 1] = c * y - sn * x;
-          }
-        }
-      }
-      // masks of the new size; the vacated slot q of every W row becomes zero again (appends add into it)
-#pragma unroll
-      for (int k = 0; k < NV; k++) {
-        eq[k] = (k == q) ? 1.0 : 0.0;
-        mk[k] = (k >= q) ? 1.0 : 0.0;
-        Wr[k] -= eq[k] * Wr[k];
-        if (PC) Wpc[k] -= eq[k] * Wpc[k];
-        if (TB) Wt[k] -= eq[k] * Wt[k];
-      }
+      for (int k = 0; k < NV; k++) mk[k] = fmad(-fl, eq[k], mk[k]);
     }
   }
   *iters_out = iters;

@@ -124,6 +124,9 @@ int host_tick_count(int kind, const double* flat215, const double* params12, int
 #include <ucontext.h>
 #define WBC_HOST_GI_STATS 1
 int g_gi_fast_trips = 0, g_gi_generic_trips = 0, g_gi_drops = 0, g_gi_force_bail = -1;
+double* g_gi_dump = nullptr;
+static double* g_gi_dump_base = nullptr;
+extern "C" void host_gi_dump(double* buf) { g_gi_dump_base = buf; }   // analysis: [n][16][16] inputs of the active set (hex path)
 extern "C" void host_gi_force_bail(int qc) { g_gi_force_bail = qc; }   // tests: leave the fast path at trip qc (a wave-mate's drop)
 extern "C" void host_gi_stats(int* out, int reset) {
   out[0] = g_gi_fast_trips; out[1] = g_gi_generic_trips; out[2] = g_gi_drops;
@@ -300,6 +303,7 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
   };
   for (int i = 0; i < n; i++) {
     A.i = i;
+    g_gi_dump = g_gi_dump_base ? g_gi_dump_base + (size_t)i * 256 : nullptr;
     ctx.count = 0;
     for (int h = 0; h < 16; h++) {
       ctx.finished[h] = false;
