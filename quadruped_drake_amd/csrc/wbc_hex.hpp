@@ -318,7 +318,9 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
     for (int k = 0; k < NV; k++) mk[k] = (k >= q) ? 1.0 : 0.0;
   }
+  WBC_GI_TIMERS;
   for (int trip = 0; generic && trip < maxit; trip++) {
+    WBC_GI_T0();
     if (!done && need_pick) {
       // most violated inactive row: argmin of the tracked values (friction slot: index h, torque slot: 16 + h)
       {
@@ -350,6 +352,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     }
     // ONE round trip through the lane crossbar per trip: the image of the (newly or previously) picked row and, for a new
     // pick, its exact value (the key carries index bits, or is the gain), its norm and -- torque rows -- its violated side
+    WBC_GI_T(0);   // pick
     const int pl = (p >= 0 && p != 16) ? (p & 15) : h;
     const bool trow = TB && p >= 32;
     double d[NV], dm[NV], d2n = 0.0;
@@ -373,6 +376,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         need_pick = false;
       }
     }
+    WBC_GI_T(1);   // fetch
     if (qo.wave_all(done)) break;
     // from here on the trip is straight-line code: a finished robot runs along with a zero step and a null reflection
     const bool live = !done;
@@ -444,6 +448,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       if (TB) yt = fmad(tz, sdt, yt);
       sp = go ? fmad(tz, d2n, sp) : sp;
     }
+    WBC_GI_T(2);   // step
     // ---- the trip's reflection: x onto slot q (append) or, after q - 1, onto the freed slot (drop)
     double x[NV], n2 = d2n, c_j = zd, c_d = sd, c_p = sdpc, c_t = sdt, c_w = 0.0, c_wp = 0.0, c_wt = 0.0;
 #pragma unroll
@@ -479,6 +484,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       if (PC) { c_p = drop ? wp1 : c_p; c_wp = drop ? wp2 : 0.0; }
       if (TB) { c_t = drop ? wt1 : c_t; c_wt = drop ? wt2 : 0.0; }
     }
+    WBC_GI_T(3);   // the drop's vector
     double eq[NV];
 #pragma unroll
     for (int k = 0; k < NV; k++) eq[k] = (k > 0) ? mk[k] - mk[k - 1] : mk[0];
@@ -564,7 +570,9 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
       for (int k = 0; k < NV; k++) mk[k] = fmad(-fl, eq[k], mk[k]);
     }
+    WBC_GI_T(4);   // reflection
   }
+  WBC_GI_TEND();
   *iters_out = iters;
   if (!done && status == ST_OK) status = ST_ITER;
   return status;

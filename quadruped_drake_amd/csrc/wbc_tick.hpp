@@ -43,16 +43,51 @@
 // Diagnostic builds only (-DWBC_STAMPS): shader-clock stamps at phase boundaries, written by lane 0
 // of each block to a side buffer that nothing else reads.  Expands to nothing in the product build.
 #if defined(WBC_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#ifdef WBC_STAMPS_GI   // slots 10..15 carry the active set's accumulated section times instead of the tick's phase stamps
+#define WBC_STAMP_OK(i) ((i) < 10)
+#else
+#define WBC_STAMP_OK(i) true
+#endif
 #define WBC_STAMP(i)                                                                                  \
   do {                                                                                                \
     __builtin_amdgcn_sched_barrier(0);                                                                \
     unsigned long long t_;                                                                            \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
-    if (threadIdx.x == 0) g_wbc_stamps[(size_t)blockIdx.x * 16 + (i)] = t_;                           \
+    if (WBC_STAMP_OK(i) && threadIdx.x == 0) g_wbc_stamps[(size_t)blockIdx.x * 16 + (i)] = t_;       \
     __builtin_amdgcn_sched_barrier(0);                                                                \
   } while (0)
 #else
 #define WBC_STAMP(i) do { } while (0)
+#endif
+// Diagnostic builds only (-DWBC_STAMPS -DWBC_STAMPS_GI): shader cycles of the sections of the active set's generic trips,
+// accumulated over a tick's trips (section i = code between timer i-1 and timer i) -> stamp slots 10 + i
+#if defined(WBC_STAMPS_GI) && defined(__HIP_DEVICE_COMPILE__)
+#define WBC_GI_TIMERS unsigned long long gt_prev_ = 0, gt_acc_[6] = {0, 0, 0, 0, 0, 0}
+#define WBC_GI_T0()                                                                                   \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(gt_prev_)::"memory");                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+#define WBC_GI_T(i)                                                                                   \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    unsigned long long t_;                                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+    gt_acc_[i] += t_ - gt_prev_;                                                                      \
+    gt_prev_ = t_;                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  } while (0)
+#define WBC_GI_TEND()                                                                                 \
+  do {                                                                                                \
+    if (threadIdx.x == 0)                                                                             \
+      for (int i_ = 0; i_ < 6; i_++) g_wbc_stamps[(size_t)blockIdx.x * 16 + 10 + i_] = gt_acc_[i_];  \
+  } while (0)
+#else
+#define WBC_GI_TIMERS do { } while (0)
+#define WBC_GI_T0() do { } while (0)
+#define WBC_GI_T(i) do { } while (0)
+#define WBC_GI_TEND() do { } while (0)
 #endif
 
 namespace wbc {
