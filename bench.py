@@ -20,11 +20,13 @@ only (`"dry_run": true`, no kernel, no throughput claim) -- tests/test_bench_lau
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -36,6 +38,17 @@ FLOPS_PER_TICK = {("mptc", 3): 37629.0, ("mptc", 5): 37703.0, ("id", 2): 35667.0
 BYTES_PER_TICK = {False: 864.0, True: 880.0}     # SURVEY.md section 8(d); True = with mu and mass scale
 PEAK_FP64_VALU_TFLOPS = 78.6                      # MI355X vector FP64 (spec); FP64 MFMA peak is the same figure
 PEAK_HBM_GBS = 8000.0
+
+
+def kernel_src_sha16():
+    """Identity of the kernel sources (csrc/ + the C ABI header): committed counter files carry it, and a counter file that
+    was collected on another build is not mixed with this build's launch time (roofline.issued becomes null instead)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "quadruped_drake_amd", "csrc")
+    for f in sorted(os.listdir(d)) + [os.path.join(ROOT, "include", "wbc.h")]:
+        with open(f if os.path.isabs(f) else os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -56,6 +69,9 @@ def parse():
     ap.add_argument("--launch-timeout", type=float, default=1800.0, help="self-launch: seconds before the children are stopped")
     ap.add_argument("--ramp-seconds", type=float, default=1.0,
                     help="untimed launches before the W warm-up steps until the GPU holds its sustained clock (DVFS ramp)")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="initialise the process group (RCCL with --backend nccl) even for ONE rank: the collective path of the "
+                         "multi-GPU run exercised on a one-GPU box")
     return ap.parse_args()
 
 
@@ -66,13 +82,14 @@ def self_launch(a):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(a.gpus):
+    out0f = tempfile.TemporaryFile(mode="w+")   # rank 0's stdout: a file, not a pipe -- library chatter (RCCL / NCCL_DEBUG, HIP
+    for r in range(a.gpus):                     # notices) of any size can never block rank 0 in write() while the parent polls
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+                                      stdout=out0f if r == 0 else sys.stderr))
     deadline = time.time() + a.launch_timeout
     rc = 0
     # poll every child: one rank dying must not leave the others waiting at the rendezvous until the timeout
@@ -84,12 +101,14 @@ def self_launch(a):
     for r, p in enumerate(procs):
         if p.poll() is None:            # stop exactly the processes started here
             p.kill()
-    out0 = procs[0].stdout.read() if procs[0].stdout else ""   # one JSON line: far below the pipe buffer
     for r, p in enumerate(procs):
         p.wait()
         if p.returncode != 0:
             sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, p.returncode))
             rc = rc or (p.returncode if p.returncode > 0 else 1)
+    out0f.seek(0)
+    out0 = out0f.read()
+    out0f.close()
     sys.stdout.write(out0)
     sys.stdout.flush()
     if rc == 0 and not any(l.startswith("{") for l in out0.splitlines()):
@@ -179,34 +198,98 @@ def cpu_baseline(batch, seconds):
 
 
 def closed_loop(shard, device, steps=300):
-    """Closed-loop rate of the same law (wbc_rollout: lookup -> tick -> forward step, one persistent launch):
-    nominal standing states with small perturbations, standing targets, dt = 1 ms (MPTC) / 5 ms (ID)."""
+    """Closed-loop rate of the same law (wbc_rollout: lookup -> tick -> forward step, one persistent launch) on a stored TROT
+    trajectory (alternating diagonal contact pairs as a TOWR trot streams them, robots at staggered phases; MPTC dt = 1 ms,
+    ID dt = 5 ms), and -- `standing` -- on nominal standing states with standing targets (the easiest workload: the friction
+    rows stay inactive)."""
     import numpy as np
     import torch
     from quadruped_drake_amd import IDController, MPTCController, workloads
     from quadruped_drake_amd.trajectory import TrunkTrajectory
     n = shard["n"]
     cls, dt = (IDController, 5e-3) if shard["kind"] == "id" else (MPTCController, 1e-3)
-    q0, v0 = workloads.nominal_state(shard["model"], n)
-    rng = np.random.default_rng(0)
-    q0[7:] += rng.uniform(-0.05, 0.05, (12, n)); v0[0:6] = rng.normal(0, 0.05, (6, n))
-    st_t = workloads.standing_targets(shard["model"], 1)[:, 0]
-    traj = TrunkTrajectory(np.zeros(0), np.zeros((0, 54)), np.zeros(0, np.uint8), wait_time=1e9, device=device,
-                           standing_targets=st_t, standing_mask=0b1111, model=shard["model"])
-    ctrl = cls(model=shard["model"], max_batch=n, device=device)
     dev = torch.device("cuda", device)
-    q = torch.tensor(q0, device=dev); v = torch.tensor(v0, device=dev); t = torch.zeros(n, dtype=torch.float64, device=dev)
-    ctrl.rollout(traj, 20, dt, q, v, t); ctrl.sync()
-    ctrl.stats(reset=True)
+    st_t = workloads.standing_targets(shard["model"], 1)[:, 0]
+
+    def run(traj, q0, v0, t0v):
+        ctrl = cls(model=shard["model"], max_batch=n, device=device)
+        q = torch.tensor(q0, device=dev); v = torch.tensor(v0, device=dev); t = torch.tensor(t0v, device=dev)
+        ctrl.rollout(traj, 20, dt, q, v, t); ctrl.sync()
+        ctrl.stats(reset=True)
+        t0 = time.perf_counter()
+        ctrl.rollout(traj, steps, dt, q, v, t); ctrl.sync()
+        el = time.perf_counter() - t0
+        s = ctrl.stats()
+        ctrl.close()
+        return {"ticks_per_s": n * steps / el, "us_per_step": el / steps * 1e6, "steps": steps, "dt": dt,
+                "status_nonzero": s["status_nonzero"], "iters_per_tick": s["iters_sum"] / max(1.0, s["ticks"])}
+
+    # trot: 4 s of samples at 1 kHz, contact pair switching every 150 ms, swing feet 2 cm up, body swaying 1 cm
+    K = 4000
+    ts = np.arange(K) * 1e-3
+    tg = np.tile(st_t, (K, 1))
+    tg[:, 0] += 0.01 * np.sin(2 * np.pi * ts / 0.3); tg[:, 3] = 0.01 * 2 * np.pi / 0.3 * np.cos(2 * np.pi * ts / 0.3)
+    masks = np.where((np.arange(K) // 150) % 2 == 0, 0b1001, 0b0110).astype(np.uint8)
+    for f in range(4):
+        sw = ((masks >> f) & 1) == 0
+        tg[sw, 18 + 9 * f + 2] += 0.02
+    rng = np.random.default_rng(1)
+    q0, v0 = workloads.nominal_state(shard["model"], n)
+    q0[7:] += rng.uniform(-0.03, 0.03, (12, n))
+    trot = TrunkTrajectory(ts, tg, masks, wait_time=0.0, device=device, standing_targets=st_t, standing_mask=0b1111, model=shard["model"])
+    out = run(trot, q0, v0, rng.uniform(0.0, 0.6, n))
+    out["scenario"] = ("%d x %s, %s, stored trot trajectory (diagonal pairs switching every 150 ms, staggered phases), targets from the "
+                       "device-side lookup, semi-implicit Euler forward step; one persistent launch for the whole rollout" % (
+                           n, shard["model"], shard["kind"].upper()))
+    rng = np.random.default_rng(0)
+    q0, v0 = workloads.nominal_state(shard["model"], n)
+    q0[7:] += rng.uniform(-0.05, 0.05, (12, n)); v0[0:6] = rng.normal(0, 0.05, (6, n))
+    stand = TrunkTrajectory(np.zeros(0), np.zeros((0, 54)), np.zeros(0, np.uint8), wait_time=1e9, device=device,
+                            standing_targets=st_t, standing_mask=0b1111, model=shard["model"])
+    out["standing"] = run(stand, q0, v0, np.zeros(n))
+    return out
+
+
+def config1_gpu(device, ticks=1200):
+    """BASELINE configs[0] on the PRODUCT path: ONE Mini Cheetah, ID law, q0 of simulate.py:171-176 with the standing targets
+    of planners/simple.py:45-85, 1200 sequential ticks (6 s at dt = 5 ms, simulate.py:20-22), each tick waited for like the
+    simulator's control loop does:  (i) the host-pointer handle make_leaf_system uses (H2D copies + launch + D2H + wait per
+    tick);  (ii) a device-pointer handle with the buffers bound once (launch + wait per tick)."""
+    import numpy as np
+    import torch
+    from quadruped_drake_amd import IDController, workloads
+    q0, v0 = workloads.nominal_state("mini_cheetah", 1)
+    tg0 = workloads.standing_targets("mini_cheetah", 1)
+    mk0 = np.array([0b1111], dtype=np.uint8)
+    res = {"workload": "BASELINE configs[0] on the product path: 1 Mini Cheetah, ID law, q0 of simulate.py:171-176, standing targets, "
+                       "%d sequential ticks, every tick waited for" % ticks}
+    c = IDController(max_batch=1, device=device, host_ptrs=True)
+    for _ in range(50):
+        tau, met, st = c.step(q0, v0, tg0, mk0); c.sync()
     t0 = time.perf_counter()
-    ctrl.rollout(traj, steps, dt, q, v, t); ctrl.sync()
+    for _ in range(ticks):
+        tau, met, st = c.step(q0, v0, tg0, mk0); c.sync()
     el = time.perf_counter() - t0
-    s = ctrl.stats()
-    ctrl.close()
-    return {"ticks_per_s": n * steps / el, "us_per_step": el / steps * 1e6, "steps": steps, "dt": dt,
-            "status_nonzero": s["status_nonzero"], "iters_per_tick": s["iters_sum"] / max(1.0, s["ticks"]),
-            "scenario": "%d x %s standing, %s, targets from the stored-trajectory lookup, semi-implicit Euler forward step; "
-                        "one persistent launch for the whole rollout" % (n, shard["model"], shard["kind"].upper())}
+    c.close()
+    res["host_pointer_handle"] = {"us_per_tick": el / ticks * 1e6, "ticks_per_s": ticks / el, "realtime_factor_at_200Hz": ticks / el / 200.0,
+                                  "status": int(st[0]), "what": "wbc_step on a WBC_HOST_PTRS handle + wbc_sync (the LeafSystem adapter's path)"}
+    dev = torch.device("cuda", device)
+    c = IDController(max_batch=1, device=device)
+    up = lambda x: torch.tensor(x, device=dev)
+    out = (torch.empty((12, 1), dtype=torch.float64, device=dev), torch.empty((4, 1), dtype=torch.float64, device=dev),
+           torch.empty((1,), dtype=torch.int32, device=dev))
+    bound = c.bind(up(q0), up(v0), up(tg0), up(mk0), out=out)
+    for _ in range(50):
+        bound.step(); c.sync()
+    t0 = time.perf_counter()
+    for _ in range(ticks):
+        bound.step(); c.sync()
+    el = time.perf_counter() - t0
+    res["device_pointer_handle_bound"] = {"us_per_tick": el / ticks * 1e6, "ticks_per_s": ticks / el,
+                                          "realtime_factor_at_200Hz": ticks / el / 200.0, "status": int(out[2][0]),
+                                          "what": "bind() once, then wbc_step + wbc_sync per tick on device-resident buffers"}
+    c.close()
+    return res
 
 
 def large_batch(device, steps=40):
@@ -254,8 +337,15 @@ def run_rank(a):
     dry = a.dry_run or (a.backend == "gloo" and not have_gpu)
     if not dry and not have_gpu:
         raise SystemExit("bench.py: no GPU visible -- the hot path has no CPU fallback (use --backend gloo for the dry-run test switch)")
-    if world > 1:
+    use_pg = world > 1 or a.force_pg
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:      # --force-pg without a launcher: a one-rank group on a free local port
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            if "MASTER_PORT" not in os.environ:
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if a.backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # RCCL over xGMI
@@ -268,8 +358,9 @@ def run_rank(a):
 
     cfg = a.config or (3 if world == 1 else 5)
     n_total = a.per_gpu * world
-    batch = workloads.make_batch(cfg, n=n_total)
-    shard = wstats.shard_batch(batch, rank, world)
+    # every rank keeps only its own contiguous window of the batch (same seeded stream as the whole batch: workloads.make_batch)
+    shard = workloads.make_batch(cfg, n=n_total, window=wstats.shard_range(n_total, rank, world))
+    batch = shard if world == 1 else None
     n = shard["n"]
 
     def sync():
@@ -277,7 +368,7 @@ def run_rank(a):
             torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
 
     if dry:
@@ -299,7 +390,7 @@ def run_rank(a):
                            "instances_per_gpu": n, "parallelism": "batch-shard x%d" % world},
                 "rollout_stats": {k: st[k] for k in ("ticks", "status_nonzero", "iters_sum", "tau_abs_max")},
                 "exchange_seconds": dt}))
-        if world > 1:
+        if use_pg:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -313,12 +404,23 @@ def run_rank(a):
     out = (torch.empty((12, n), dtype=torch.float64, device=dev), torch.empty((4, n), dtype=torch.float64, device=dev),
            torch.empty((n,), dtype=torch.int32, device=dev))
 
+    # cold figure first: W warm-up steps, then K timed steps BEFORE any clock ramp (what a process that ticks only now and
+    # then would see); reported as value_cold beside value
+    bound = ctrl.bind(q, v, tg, mask, mu, ms, out=out)          # tensors validated once: the loops below are the C ABI only
+    for _ in range(a.warmup):
+        bound.step()
+    sync(); barrier(); sync()
+    t0c = time.perf_counter()
+    bound.time_steps(a.steps, wait=False)
+    ctrl.stats()
+    ms_cold = bound.time_steps_result()
+    sync(); barrier(); sync()
+    dt_cold = time.perf_counter() - t0c
     # clock ramp: the GPU raises its clock over the first ~1 s of sustained load (measured: 29.4 -> 26.7 us per launch,
     # profiles/r02/tail_experiment.md); steady state is what a control loop sees, so the ramp is not part of the W + K steps
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < a.ramp_seconds:
         ctrl.time_steps(100, q, v, tg, mask, mu, ms, out=out)
-    bound = ctrl.bind(q, v, tg, mask, mu, ms, out=out)          # tensors validated once: the loop below is the C ABI only
     for _ in range(a.warmup):
         bound.step()
     wstats.all_gather_stats(ctrl.stats(), device=cdev)            # warm the statistics exchange (RCCL channel set-up) as well
@@ -331,10 +433,14 @@ def run_rank(a):
     ms_per_launch = bound.time_steps_result()    # the events completed before the statistics did: no second wait
     sync(); barrier(); sync()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt, ms_per_launch], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt, ms_per_launch = float(tt[0]), float(tt[1])
+    per_rank_kernel_ms = [ms_per_launch]
+    if use_pg:
+        tt = torch.tensor([dt, ms_per_launch, dt_cold, ms_cold], dtype=torch.float64, device=cdev)
+        parts = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(parts, tt)
+        allr = torch.stack(parts).cpu().numpy()
+        per_rank_kernel_ms = [float(x) for x in allr[:, 1]]
+        dt, ms_per_launch, dt_cold, ms_cold = (float(x) for x in allr.max(0))     # MAX over ranks
     # per-launch distribution (outside the timed region): one HIP event between every two launches
     each, _ = ctrl.time_steps_each(a.steps, q, v, tg, mask, mu, ms, out=out)
 
@@ -362,24 +468,30 @@ def run_rank(a):
         issued = None
         try:
             if shard["kind"] == "mptc" and cfg == 3 and n == 4096:
-                with open(os.path.join(ROOT, "profiles", "r02", "hex_pmc.json")) as f:
-                    pc = json.load(f)["counters"]
+                with open(os.path.join(ROOT, "profiles", "r03", "hex_pmc.json")) as f:
+                    pj = json.load(f)
+                if pj.get("kernel_src_sha16") != kernel_src_sha16():
+                    raise KeyError("counter file is from another kernel build")
+                pc = pj["counters"]
                 g = lambda k: pc[k]["mean_per_launch"]
                 ex = 64.0 * (2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64"))
                 issued = {"executed_fp64_flops_per_launch": ex, "executed_TFLOPs": ex / sec / 1e12,
                           "executed_frac_of_peak": ex / sec / 1e12 / PEAK_FP64_VALU_TFLOPS,
                           "redundancy": ex / (flops * n), "valu_insts_per_wavefront": g("SQ_INSTS_VALU") / g("SQ_WAVES"),
                           "mfma_insts": g("SQ_INSTS_MFMA"),
-                          "source": "profiles/r02/hex_pmc.json (rocprofv3 --pmc, separate passes of this command)"}
+                          "source": "profiles/r03/hex_pmc.json (rocprofv3 --pmc, separate passes of this command; same kernel "
+                                    "sources: sha16 %s)" % pj["kernel_src_sha16"]}
         except (OSError, ValueError, KeyError):
             pass
         line = {
             "metric": "whole-body-QP control ticks/s at N=4096 Mini Cheetah",
             "value": n_total * a.steps / dt, "unit": "ticks/s",
+            "value_cold": n_total * a.steps / dt_cold, "kernel_ms_cold": ms_cold,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "backend": a.backend, "ramp_seconds": a.ramp_seconds,
-            "ranks_seen": seen, "per_rank_ticks": [r["ticks"] for r in per_rank],
+            "ranks_seen": seen, "per_rank_ticks": [r["ticks"] for r in per_rank], "per_rank_kernel_ms": per_rank_kernel_ms,
+            "process_group": (a.backend if use_pg else None), "kernel_src_sha16": kernel_src_sha16(),
             "config": {"workload": "BASELINE configs[%d]: %d x %s, %s controller, %s" % (
                 cfg - 1, n_total, shard["model"], shard["kind"].upper(),
                 "trot contact masks" if cfg != 2 else "4-contact stand"),
@@ -406,6 +518,7 @@ def run_rank(a):
         if world == 1 and not a.no_cpu_baseline:
             line["n32768"] = large_batch(local)                       # informational, outside the timed region
             line["closed_loop"] = closed_loop(shard, local)           # informational, outside the timed region
+            line["config1_gpu"] = config1_gpu(local)                  # BASELINE configs[0] on the product path (informational)
             line["cpu_baseline"] = cpu_baseline(batch, a.cpu_seconds)
             # parity beside the number: full torque vector (tier ii) and the solver-independent accelerations (tier i)
             from oracle import oracle_py as orc
@@ -436,7 +549,7 @@ def run_rank(a):
             line["vdot_rel_err_vs_cpu_ref_qp"] = worst          # tier (i): solver-independent part of the solution
         print(json.dumps(line))
     ctrl.close()
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

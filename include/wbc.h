@@ -23,7 +23,10 @@
  *   contact_mask [n]   bit i set = foot i of [LF RF LH RH] in contact (`contact_states`)
  *   tau      [12][ld]  joint torques in ACTUATOR order             (basic_controller.py:37-40,320)
  *   metrics  [4][ld]   V, err, res, Vdot                            (basic_controller.py:47-50,283)
- *   status   [n]       0 optimal, 1 iteration cap, 2 singular / infeasible (tau and the accelerations are 0 then)
+ *   status   [n]       0 optimal, 1 iteration cap, 2 singular / infeasible (tau and the accelerations are 0 then),
+ *                      3 ill-conditioned (MPTC / PC only: |sin(knee)| < 1e-4 on some leg, where the law's own
+ *                      inv(J M^-1 J') (mptc_controller.py:237-238) loses its digits; tau, metrics and accelerations ARE
+ *                      written, but neither this library nor a dense restatement can vouch for them)
  *                      (the reference asserts result.is_success(): inverse_dynamics_controller.py:224)
  * Joint rows of q/v are mapped through model.q_perm (canonical joint j is read from joint row
  * q_perm[j]); torque row k is canonical joint act_perm[k]  (basic_controller.py:310-313).

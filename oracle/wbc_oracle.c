@@ -832,6 +832,14 @@ static int mptc_like_control_law(const orc_model* m, const orc_params* p, const 
   mm(mt, 18, 18, J, Minv, JMi);          /* J Minv */
   mmt(mt, 18, mt, JMi, J, Lam);          /* J Minv J' */
   bad |= mat_inv(mt, Lam);               /* Lambda */
+  /* the product's status convention (include/wbc.h), mirrored: a leg whose 3x3 foot Jacobian block is singular to rounding
+   * (|det| <= 1e-12: an exactly straight knee) makes J Minv J' singular up to rounding noise -- mat_inv above may or may not
+   * notice -- and is reported as status 2 with zero torques, not solved */
+  for (int l = 0; l < 4; l++) {
+    const double* B = T->J_feet[l] + 6 + 3 * l;   /* rows 18 apart */
+    double det = B[0] * (B[19] * B[38] - B[20] * B[37]) - B[1] * (B[18] * B[38] - B[20] * B[36]) + B[2] * (B[18] * B[37] - B[19] * B[36]);
+    if (!(fabs(det) > 1e-12)) bad = 1;
+  }
   mtm(18, mt, mt, JMi, Lam, Jbar);       /* Jbar = Minv J' Lambda  (18 x mt); Minv symmetric */
   mm(mt, 18, 18, JMi, C, Qm);            /* Q = J Minv C - Jd */
   for (int i = 0; i < mt * 18; i++) Qm[i] -= Jd[i];
@@ -920,6 +928,12 @@ static int mptc_like_control_law(const orc_model* m, const orc_params* p, const 
   }
   int status = bad ? 2 : solve_and_extract(p, qp, tau); /* :294-296 */
   if (bad) { for (int k = 0; k < 12; k++) tau[k] = 0; qp->status = 2; }
+  /* the product's status convention (include/wbc.h), mirrored so that the checker and the checked agree on it: a solved tick
+   * with a nearly straight knee (|sin| < 1e-4: inv(J Minv J') above has lost its digits) is reported as 3 */
+  if (status == 0)
+    for (int l = 0; l < 4; l++)
+      if (fabs(sin(q[7 + 3 * l + 2])) < 1e-4) status = 3;
+  if (status == 3) qp->status = 3;
   /* :298-308 logging (pc_controller.py:240-252 is identical) */
   if (metrics) {
     double V = 0, err = 0, Vdot = 0;

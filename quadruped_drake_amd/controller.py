@@ -45,7 +45,13 @@ def pack_trunk_input(trunk_data):
 
 
 class SolverError(AssertionError):
-    """Mirrors `assert result.is_success()` (inverse_dynamics_controller.py:224)."""
+    """Mirrors `assert result.is_success()` (inverse_dynamics_controller.py:224).  args = (text, status, tau): for status 3
+    (MPTC / PC with a nearly straight knee: the law's own inv(J M^-1 J') is ill-conditioned) the torques were computed and
+    ride along, but nothing vouches for them."""
+
+
+STATUS_TEXT = {1: "iteration cap", 2: "singular / infeasible: torques and accelerations are zero",
+               3: "ill-conditioned: |sin(knee)| < 1e-4 on a leg under a task-space law; torques written but not trustworthy"}
 
 
 class BatchedController:
@@ -118,6 +124,8 @@ class BatchedController:
         tdt = {np.float64: torch.float64, np.uint8: torch.uint8, np.int32: torch.int32}[dtype]
         if not (isinstance(a, torch.Tensor) and a.is_cuda and a.dtype == tdt and a.is_contiguous()):
             raise ValueError("%s: expected a contiguous CUDA tensor of dtype %s" % (name, tdt))
+        if a.device.index != self.device:
+            raise ValueError("%s: tensor lives on cuda:%s, this controller's handle on cuda:%d" % (name, a.device.index, self.device))
         if tuple(a.shape) != ((rows, n) if rows else (n,)):
             raise ValueError("%s: expected shape %s, got %s" % (name, (rows, n) if rows else (n,), tuple(a.shape)))
         return a, C.c_void_p(a.data_ptr())
@@ -299,7 +307,7 @@ class BatchedController:
             self.sync()
             tau, met, st = outs[0][:, 0].cpu().numpy(), outs[1][:, 0].cpu().numpy(), int(outs[2][0])
         if st != 0:
-            raise SolverError("whole-body QP failed with status %d" % st)
+            raise SolverError("whole-body QP failed with status %d (%s)" % (st, STATUS_TEXT.get(st, "unknown")), st, tau)
         self.V, self.err, self.res, self.Vdot = (float(x) for x in met)
         return tau
 

@@ -662,6 +662,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   const bool colv = sb < 3;  // owns a z-space column (else: the right-hand-side / ab0 column, or delta)
   const bool cold = (KIND == KIND_CLF) && h == HEX_DELTA_LANE;   // owns the delta column (CLF law)
   int status = ST_OK;
+  bool illc = false;
   WBC_HCUT_AT(0, in(0) + in(20) + in(40) + in(37 + 18 + 9 * l + sb) + mu + mass_scale + m.gravity)
   // ---------------- state (replicated on the 16 lanes)
   double R0[9];
@@ -757,6 +758,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
         wbc_sincos(pick3(sb, th[0], th[1], th[2]), so, co);
         for (int k = 0; k < 3; k++) { sn[k] = qo.leg_bcast(so, k); cs[k] = qo.leg_bcast(co, k); }
         if ((KIND == KIND_ID || KIND == KIND_CLF) && !ct) knee_clamp(sn[2], cs[2]);   // swing legs of the ID-type laws (wbc_tick.hpp)
+        if (MP) illc = qo.any16(fabs(sn[2]) < KNEE_ILLCOND);   // a nearly straight knee anywhere: reported as status 3 (wbc_tick.hpp)
       }
       leg_fk_xyy(m, l, R0, sn, cs, K);
     }
@@ -1262,6 +1264,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC || (WBC_GAIN_ID && KIND == KIND_ID)) && !TB>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt);
     }
     if (st != ST_OK) status = st;
+    if (status == ST_OK && illc) status = ST_ILLCOND;
   }
   *iters_out = iters;
   WBC_STAMP(6);

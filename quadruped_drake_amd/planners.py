@@ -132,6 +132,8 @@ class TowrTrunkPlanner(BasicTrunkPlanner):
         self.towr_data.append(msg)
         self.traj_finished = msg["finished"]
         self._traj = None
+        if self.traj_finished:          # the reference computes it once the stream has finished (planners/towr.py:31-32, 67-68)
+            self.u2_max = self.ComputeMaxControlInputs()
 
     def ComputeMaxControlInputs(self):
         """max over the samples of the 2-norm of [foot accelerations (LF RF LH RH); rpydd; pdd]  (planners/towr.py:71-90)."""

@@ -48,8 +48,9 @@ def all_gather_stats(stats, device=None):
     Returns (reduced dict, per-rank list of dicts, world size seen by the process group)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return dict(stats), [dict(stats)], 1
+    # an initialised group of ONE rank still goes through the collective (bench.py --force-pg: the RCCL path on a one-GPU box)
     s, m = pack(stats)
     t = torch.tensor(np.concatenate([s, m]), dtype=torch.float64, device=device)
     parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]

@@ -52,8 +52,11 @@ def nominal_state(model="mini_cheetah", n=1):
     return q, v
 
 
-def make_batch(config, n=None, seed=None, model=None):
-    """config in {2, 3, 4, 5} (BASELINE.json configs[1..4]).  Returns a dict."""
+def make_batch(config, n=None, seed=None, model=None, window=None):
+    """config in {2, 3, 4, 5} (BASELINE.json configs[1..4]).  Returns a dict.
+    window = (lo, hi): only instances lo..hi-1 of the n-instance batch are KEPT (identical values: every array is drawn
+    from the one seeded stream exactly as for the whole batch and cut right after its draw, so a rank of a sharded run never
+    holds more than one full-width array at a time; out["n"] = hi - lo, out["n_total"] = n)."""
     defaults = {2: (1024, 1001, "mini_cheetah", "id"), 3: (4096, 1002, "mini_cheetah", "mptc"),
                 4: (4096, 1003, "anymal_b", "mptc"), 5: (32768, 1004, "mini_cheetah", "mptc")}
     dn, dseed, dmodel, kind = defaults[config]
@@ -63,37 +66,41 @@ def make_batch(config, n=None, seed=None, model=None):
     rng = np.random.default_rng(seed)
     trot = config in (3, 4, 5)
     vsig = 0.5 if trot else 0.3
+    lo, hi = (0, n) if window is None else (int(window[0]), int(window[1]))
+    assert 0 <= lo <= hi <= n
+    w = hi - lo
+    cut = lambda a: a[..., lo:hi]          # every draw has the full width (same stream), only the window is kept
 
-    rpy = rng.uniform(-0.2, 0.2, (3, n))
-    q = np.zeros((19, n))
+    rpy = cut(rng.uniform(-0.2, 0.2, (3, n)))
+    q = np.zeros((19, w))
     q[0:4] = rpy_to_quat(rpy)
-    q[4:6] = rng.uniform(-1.0, 1.0, (2, n))
+    q[4:6] = cut(rng.uniform(-1.0, 1.0, (2, n)))
     h0 = NOMINAL_HEIGHT[model]
-    q[6] = rng.uniform(h0 - 0.03, h0 + 0.03, n)
-    q[7:] = NOMINAL_JOINTS[model][:, None] + rng.uniform(-0.25, 0.25, (12, n))
-    v = rng.normal(0.0, vsig, (18, n))
+    q[6] = cut(rng.uniform(h0 - 0.03, h0 + 0.03, n))
+    q[7:] = NOMINAL_JOINTS[model][:, None] + cut(rng.uniform(-0.25, 0.25, (12, n)))
+    v = np.ascontiguousarray(cut(rng.normal(0.0, vsig, (18, n))))
 
-    t = np.zeros((54, n))
-    t[0:3] = q[4:7] + rng.normal(0, 0.02, (3, n))         # p_body
-    t[3:9] = rng.normal(0, 0.1, (6, n))                    # pd, pdd
-    t[9:12] = rng.normal(0, 0.05, (3, n))                  # rpy target
-    t[12:18] = rng.normal(0, 0.1, (6, n))                  # rpyd, rpydd
+    t = np.zeros((54, w))
+    t[0:3] = q[4:7] + cut(rng.normal(0, 0.02, (3, n)))         # p_body
+    t[3:9] = cut(rng.normal(0, 0.1, (6, n)))                    # pd, pdd
+    t[9:12] = cut(rng.normal(0, 0.05, (3, n)))                  # rpy target
+    t[12:18] = cut(rng.normal(0, 0.1, (6, n)))                  # rpyd, rpydd
     if trot:
-        mask = np.where(rng.random(n) < 0.5, TROT_MASKS[0], TROT_MASKS[1]).astype(np.uint8)
+        mask = np.where(cut(rng.random(n)) < 0.5, TROT_MASKS[0], TROT_MASKS[1]).astype(np.uint8)
     else:
-        mask = np.full(n, 0b1111, dtype=np.uint8)
+        mask = np.full(w, 0b1111, dtype=np.uint8)
     for i in range(4):
-        p = np.tile(STAND_FEET[model][i][:, None], (1, n))
+        p = np.tile(STAND_FEET[model][i][:, None], (1, w))
         p[0:2] += q[4:6]
         swing = ((mask >> i) & 1) == 0
-        p[2] = np.where(swing, rng.uniform(0.05, 0.10, n), 0.0)
+        p[2] = np.where(swing, cut(rng.uniform(0.05, 0.10, n)), 0.0)
         t[18 + 9 * i:21 + 9 * i] = p
         sig = np.where(swing, 0.3, 0.1)
-        t[21 + 9 * i:24 + 9 * i] = rng.normal(0, 1.0, (3, n)) * sig
-        t[24 + 9 * i:27 + 9 * i] = rng.normal(0, 0.1, (3, n))
-    out = dict(config=config, n=n, seed=seed, model=model, kind=kind, q=q, v=v, targets=t, mask=mask,
+        t[21 + 9 * i:24 + 9 * i] = cut(rng.normal(0, 1.0, (3, n))) * sig
+        t[24 + 9 * i:27 + 9 * i] = cut(rng.normal(0, 0.1, (3, n)))
+    out = dict(config=config, n=w, n_total=n, window=(lo, hi), seed=seed, model=model, kind=kind, q=q, v=v, targets=t, mask=mask,
                mu=None, mass_scale=None)
     if config == 5:
-        out["mu"] = rng.uniform(0.4, 1.0, n)
-        out["mass_scale"] = rng.uniform(0.8, 1.2, n)
+        out["mu"] = np.ascontiguousarray(cut(rng.uniform(0.4, 1.0, n)))
+        out["mass_scale"] = np.ascontiguousarray(cut(rng.uniform(0.8, 1.2, n)))
     return out

@@ -153,6 +153,19 @@ class RefPlant:
     def GetVelocities(self, ctx):
         return self._vec(ctx.v)
 
+    def GetJointByName(self, name):
+        """The joint's place in the plant's own numbering (what make_leaf_system and tools/drake_crosscheck.py read)."""
+        names = [l["joint"] for leg in orc.load_model_json(self.model_name)["legs"] for l in leg["links"]]
+        j = names.index(name)
+
+        class _J:
+            def velocity_start(_s):
+                return 6 + self.order[j]
+
+            def position_start(_s):
+                return 7 + self.order[j]
+        return _J()
+
     def MakeActuationMatrix(self):
         B = np.zeros((18, 12))
         for k, j in enumerate(self.act_joint):

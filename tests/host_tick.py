@@ -15,7 +15,7 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_ROOT, "tools", "libhost_tick.so")
-        srcs = [os.path.join(_ROOT, "tools", "host_tick.cpp"),
+        srcs = [os.path.join(_ROOT, "tools", "host_tick.cpp"), os.path.join(_ROOT, "tools", "wbc_scalar_tick.hpp"),
                 os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_tick.hpp"),
                 os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_model.hpp"),
                 os.path.join(_ROOT, "quadruped_drake_amd", "csrc", "wbc_hex.hpp"),

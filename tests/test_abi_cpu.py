@@ -95,3 +95,18 @@ def test_workload_generators_are_seeded_and_shaped():
     c = workloads.make_batch(5, n=32)
     assert c["mu"].min() >= 0.4 and c["mu"].max() <= 1.0 and c["mass_scale"].min() >= 0.8
     assert (workloads.make_batch(2, n=8)["mask"] == 0b1111).all()
+
+
+def test_dpp_hazard_lint_flags_a_violation_and_passes_clean_code(tmp_path):
+    """tools/dpp_lint.py (run by build() over the device assembly): a VALU write followed within two wait states by a DPP read
+    of the same register is reported; the same code behind an s_nop, or with another register, is not."""
+    import subprocess, sys
+    tool = os.path.join(ROOT, "tools", "dpp_lint.py")
+    dirty = tmp_path / "dirty.s"
+    dirty.write_text("_Zk:\n\tv_add_f64 v[2:3], v[4:5], v[6:7]\n\tv_fmac_f64_dpp v[8:9], v[2:3], v[10:11] row_newbcast:3 row_mask:0xf bank_mask:0xf\n")
+    clean = tmp_path / "clean.s"
+    clean.write_text("_Zk:\n\tv_add_f64 v[2:3], v[4:5], v[6:7]\n\ts_nop 1\n\tv_fmac_f64_dpp v[8:9], v[2:3], v[10:11] row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+                     "\tv_add_f64 v[12:13], v[4:5], v[6:7]\n\tv_fmac_f64_dpp v[8:9], v[14:15], v[12:13] row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
+    assert subprocess.run([sys.executable, tool, str(dirty)], capture_output=True).returncode == 1
+    r = subprocess.run([sys.executable, tool, str(clean)], capture_output=True, text=True)
+    assert r.returncode == 0 and "2 fused" in r.stdout

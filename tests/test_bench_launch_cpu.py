@@ -34,6 +34,14 @@ def test_self_launch_propagates_a_failing_rank():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_one_rank_process_group_gloo_dry_run():
+    """--force-pg: ONE rank still initialises the group and sends its statistics through the collective (the RCCL path's CPU twin)."""
+    r = _run(["--gpus", "1", "--force-pg", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--per-gpu", "64"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["dry_run"] is True and d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["per_rank_ticks"] == [64.0 * 3]
+
+
 def test_single_rank_without_gpu_fails_loudly():
     import torch
     if torch.cuda.is_available():
@@ -56,3 +64,45 @@ def test_self_launch_two_ranks_compute_on_the_gpu():
     assert "dry_run" not in d and d["n_gpus"] == 2 and d["ranks_seen"] == 2
     assert d["per_rank_ticks"] == [512.0 * 5, 512.0 * 5] and d["rollout_stats"]["ticks"] == 2 * 512 * 5
     assert d["status_nonzero"] == 0 and d["value"] > 0 and d["config"]["domain_randomised"] is True
+
+
+@pytest.mark.gpu
+def test_rccl_one_rank_group_runs_the_statistics_collective():
+    """RCCL itself (backend "nccl" on ROCm) before the multi-GPU node does: a ONE-rank group initialised exactly like bench.py's
+    ranks (device_id=, 127.0.0.1 rendezvous, HSA_ENABLE_IPC_MODE_LEGACY=0) runs stats.all_gather_stats on DEVICE tensors."""
+    code = r'''
+import os, socket, sys
+sys.path.insert(0, %r)
+with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+    s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+from quadruped_drake_amd import stats
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+local = dict(ticks=4096.0, status_nonzero=3.0, iters_sum=8000.0, tau_abs_sum=1.5e5, tau_abs_max=41.5, err_sum=2.0,
+             mask_count=[float(k) for k in range(16)])
+red, per_rank, seen = stats.all_gather_stats(local, device=torch.device("cuda", 0))
+assert seen == 1 and len(per_rank) == 1 and red == local and per_rank[0] == local, (red, local)
+t = torch.ones(8, dtype=torch.float64, device="cuda:0"); dist.all_reduce(t); torch.cuda.synchronize()
+assert float(t.sum()) == 8.0
+dist.barrier(); dist.destroy_process_group()
+print("rccl ok")
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_bench_one_gpu_through_the_process_group_branch():
+    """bench.py --gpus 1 --force-pg: the N > 1 code path (RCCL init with device_id=, the device-side statistics gather, the
+    per-rank timing gather) on the one GPU of this box; the line carries ranks_seen / per_rank_* for N = 1."""
+    r = _run(["--gpus", "1", "--force-pg", "--steps", "10", "--warmup", "2", "--ramp-seconds", "0.2", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["process_group"] == "nccl" and d["n_gpus"] == 1 and d["ranks_seen"] == 1
+    assert d["per_rank_ticks"] == [4096.0 * 10] and len(d["per_rank_kernel_ms"]) == 1 and d["per_rank_kernel_ms"][0] > 0
+    assert d["status_nonzero"] == 0 and d["value"] > 0 and d["value_cold"] > 0
+    assert d["roofline"]["traffic"] is not None

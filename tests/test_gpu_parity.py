@@ -215,6 +215,45 @@ def test_single_robot_control_law_mirrors_reference_signature():
         assert st_o == 0 and np.abs(u - u_o).max() < 1e-6 * (1 + np.abs(u_o).max())
 
 
+def test_ill_conditioned_ticks_are_reported_not_hidden():
+    """MPTC / PC with |sin(knee)| < 1e-4 on a leg: status 3 on the device exactly where the oracle reports it, torques and
+    metrics written (finite, non-zero); the single-robot mirror raises SolverError carrying status and torques; ID / CLF on the
+    same states: status 0 and parity (include/wbc.h, mptc_controller.py:237-238)."""
+    from oracle import oracle_py as orc
+    from quadruped_drake_amd import IDController, MPTCController, PCController, CLFController, workloads, SolverError
+    torch = _torch()
+    b = workloads.make_batch(3, n=64)
+    q = b["q"].copy()
+    q[7 + 2, 0::4] = 5e-5; q[7 + 3 * 3 + 2, 1::4] = -3e-6; q[7 + 2, 2::4] = 1e-3
+    up = lambda x: torch.tensor(x, device="cuda:0")
+    for cls, kind in ((MPTCController, "mptc"), (PCController, "pc"), (IDController, "id"), (CLFController, "clf")):
+        c = cls(max_batch=64, device=0)
+        tau, met, st = c.step(up(q), up(b["v"]), up(b["targets"]), up(b["mask"])); c.sync()
+        tau, met, st = tau.cpu().numpy(), met.cpu().numpy(), st.cpu().numpy()
+        tau_o, met_o, st_o = orc.step_batch(kind, orc.model("mini_cheetah"), orc.params(kind), q, b["v"], b["targets"], b["mask"])
+        assert (st == st_o).all()
+        if kind in ("mptc", "pc"):
+            assert (st[0::4] == 3).all() and (st[1::4] == 3).all() and (st[2::4] == 0).all() and (st[3::4] == 0).all()
+            assert np.isfinite(tau).all() and np.isfinite(met).all() and (np.abs(tau).max(0) > 0).all()
+            assert c.stats()["status_nonzero"] == 32
+        else:
+            assert (st == 0).all()
+        ok = st == 0
+        r = np.abs(tau[:, ok] - tau_o[:, ok]).max(0) / np.maximum(np.abs(tau_o[:, ok]).max(0), 1e-3)
+        assert r.max() < 1e-4
+        c.close()
+    c = MPTCController(max_batch=1, device=0)
+    d = {}
+    for i, f in enumerate(("lf", "rf", "lh", "rh")):
+        d["p_" + f] = b["targets"][18 + 9 * i:21 + 9 * i, 0]; d["pd_" + f] = np.zeros(3); d["pdd_" + f] = np.zeros(3)
+    d.update(rpy_body=np.zeros(3), p_body=b["targets"][0:3, 0], rpyd_body=np.zeros(3), pd_body=np.zeros(3),
+             rpydd_body=np.zeros(3), pdd_body=np.zeros(3), contact_states=[True, False, False, True])
+    with pytest.raises(SolverError) as ei:
+        c.ControlLaw(q[:, 0], b["v"][:, 0], d)
+    assert ei.value.args[1] == 3 and "ill-conditioned" in ei.value.args[0] and np.isfinite(ei.value.args[2]).all()
+    c.close()
+
+
 @pytest.mark.parametrize("cfg,n", [(3, 4096), (5, 32768)])
 def test_full_size_properties(cfg, n):
     """BASELINE full sizes: size-independent properties instead of the (slow) oracle."""
@@ -267,7 +306,8 @@ def test_full_size_oracle_parity(cfg, kind, n):
     from quadruped_drake_amd import workloads
     b = workloads.make_batch(cfg, n=n)
     tau, met, st, stats = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
-    cores = len(os.sched_getaffinity(0))
+    import bench
+    cores = bench.cpu_limits()["usable"]        # the cgroup quota, not the affinity mask (16 of 256 visible CPUs on the pool's boxes)
     tau_o, met_o, st_o = orc.step_batch(kind, orc.model(b["model"]), orc.params(kind), b["q"], b["v"], b["targets"], b["mask"],
                                         b["mu"], b["mass_scale"], nthreads=cores)
     assert (st == 0).all() and (st_o == 0).all()

@@ -146,6 +146,30 @@ def test_straight_knee():
         assert (tau[:, :2] == 0).all() and np.isfinite(tau[:, [0, 1, 3, 4, 5, 6, 7]]).all()
 
 
+def test_nearly_straight_knee_is_reported_as_ill_conditioned():
+    """MPTC / PC invert J M^-1 J' (mptc_controller.py:237-238): below |sin(knee)| = 1e-4 the tick is solved and written
+    but reported as status 3 -- by the kernel math and by the oracle alike (include/wbc.h); the ID-type laws, which agree
+    with the dense restatement down to 1e-8 rad, stay at status 0.  Just above the threshold the status is 0 and the
+    torques agree (profiles/r03/singular_envelope.md)."""
+    b = workloads.make_batch(3, n=8)
+    t = orc.load_model_json("mini_cheetah")
+    q = b["q"].copy()
+    q[7 + 2, 0] = 5e-5          # LF knee below the threshold
+    q[7 + 3 * 3 + 2, 1] = -3e-6   # RH knee, negative side
+    q[7 + 2, 2] = 2e-4          # above it
+    for kind in ("mptc", "pc"):
+        tau_o, _, st_o = orc.step_batch(kind, orc.model("mini_cheetah"), orc.params(kind), q, b["v"], b["targets"], b["mask"])
+        for kw in ({}, {"hexv": True}):
+            tau, met, st, it = ht.run(kind, t["flat"], q, b["v"], b["targets"], b["mask"], **kw)
+            assert st.tolist() == [3, 3, 0, 0, 0, 0, 0, 0] == st_o.tolist()
+            assert np.isfinite(tau).all() and (np.abs(tau[:, :2]).max(0) > 0).all()   # written, not zeroed
+        assert rel_err(tau[:, 2:], tau_o[:, 2:]).max() < 1e-5   # 16-lane form
+    for kind in ("id", "clf"):
+        tau, met, st, it = ht.run(kind, t["flat"], q, b["v"], b["targets"], b["mask"], hexv=True)
+        tau_o, _, st_o = orc.step_batch(kind, orc.model("mini_cheetah"), orc.params(kind), q, b["v"], b["targets"], b["mask"])
+        assert (st == 0).all() and (st_o == 0).all() and rel_err(tau, tau_o).max() < 1e-5
+
+
 def test_nan_state_is_reported_with_zero_outputs():
     """A non-finite state cannot be solved: status 2, zero torques and zero accelerations (never NaN outputs)."""
     b = workloads.make_batch(3, n=4)

@@ -1,5 +1,5 @@
 // host_tick.cpp -- TEST/ANALYSIS TOOL, not product code.
-// Instantiates the kernel math (quadruped_drake_amd/csrc/wbc_tick.hpp) on the host:
+// Instantiates the kernel math (quadruped_drake_amd/csrc/wbc_tick.hpp, wbc_hex.hpp; tools/wbc_scalar_tick.hpp) on the host:
 //   * with `double`, so the tick arithmetic can be debugged against the oracle without a GPU;
 //   * with an operation-counting scalar, which yields the frozen flops/tick figure that
 //     bench.py's roofline uses.
@@ -8,6 +8,7 @@
 #include <stdint.h>
 #include <string.h>
 #include "../quadruped_drake_amd/csrc/wbc_model.hpp"
+#include "wbc_scalar_tick.hpp"
 
 struct Cnt {  // counts[0]=add/sub, 1=mul, 2=div, 3=sqrt, 4=trig(sin/cos/atan2), 5=cmp
   double v;

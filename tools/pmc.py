@@ -17,7 +17,9 @@ ap.add_argument("rest", nargs=argparse.REMAINDER)
 a = ap.parse_args()
 rest = [x for x in a.rest if x != "--"]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-res = {"bench_args": rest, "counters": {}}
+sys.path.insert(0, root)
+import bench as _bench   # kernel_src_sha16(): the identity of the kernel sources these counters belong to (no torch import)
+res = {"bench_args": rest, "kernel_src_sha16": _bench.kernel_src_sha16(), "counters": {}}
 env = dict(os.environ, TMPDIR="/tmp")
 for gi, grp in enumerate(a.groups):
     d = tempfile.mkdtemp(prefix="pmc%d_" % gi, dir="/tmp")
