@@ -617,7 +617,7 @@ template <int NR> WBC_HD double solve6np(double (*Ab)[6 + NR]) {
 // (G_b for the MPTC rows) wait in LDS instead of occupying 2 VGPRs each -- a spilled VGPR costs an
 // exposed L2 round trip (~0.4 us measured, profiles/r02), an LDS read ~100 cycles.  All 16 lanes
 // write the same value to the same address.  Host: a plain array.
-enum { PK_GS = 0, PK_N = 36 };
+enum { PK_GS = 0, PK_ST = 36, PK_N = 36 + 21 };   // G_b (MPTC rows) | state values that sleep through the leg phase
 // Lane-private park (lput / lget): what only the output stage needs again (own rows of the torque map, own column of
 // B, the metrics ...) leaves the registers for the QR and the active set -- one ds_write_b64 / ds_read_b64 per double
 // instead of the two v_accvgpr_write + two v_accvgpr_read the register allocator spends on a value it keeps in an
@@ -730,6 +730,11 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       }
     }
   }
+#ifndef WBC_NO_PARK_STATE
+  // robot-level values that the leg phase does not touch wait in LDS (the leg phase is the register peak of the tick)
+  for (int i = 0; i < 6; i++) { pk.put(PK_ST + i, xt_b[i]); pk.put(PK_ST + 6 + i, xdd_b[i]); pk.put(PK_ST + 12 + i, bI[i]); }
+  for (int i = 0; i < 3; i++) pk.put(PK_ST + 18 + i, bmc[i]);
+#endif
   WBC_STAMP(10);
   WBC_HCUT_AT(1, xt_b[0] + xt_b[4] + xdt_b[1] + xdt_b[5] + xdd_b[2] + ades[1] + bI[3] + bmc[1] + R0[5] + rpyd[0] + E[3])
   // ---------------- own leg (replicated on its four sub-lanes unless noted)
@@ -869,6 +874,10 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       Dcol[j] = ct ? -pick3(sb, Jl[j], Jl[3 + j], Jl[6 + j]) : pick3(sb, Pm[3 * j], Pm[3 * j + 1], Pm[3 * j + 2]);
     }
   }
+#ifndef WBC_NO_PARK_STATE
+  for (int i = 0; i < 6; i++) { xt_b[i] = pk.get(PK_ST + i); xdd_b[i] = pk.get(PK_ST + 6 + i); bI[i] = pk.get(PK_ST + 12 + i); }
+  for (int i = 0; i < 3; i++) bmc[i] = pk.get(PK_ST + 18 + i);
+#endif
   WBC_STAMP(11);
   WBC_HCUT_AT(2, X[0] + X[7] + X[17] + Y[3] + Y[16] + hbN[0] + hbN[5] + lm + lh[1] + lI[3] + Cb_leg[2] + Cl[1] + xi[0] + t0_own + Yrow[2] + Drow[1] + Ji[4] + Mll6[2] + jdxi[0] + xt_s[0] + xdt_s[1] + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1])
   // ---------------- base: bias wrench, composite inertia -> Gs = G_b, kv
@@ -885,12 +894,20 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       cross(bmc, g3, t4);
       for (int i = 0; i < 3; i++) { hb[i] = t3[i] + t4[i]; hb[3 + i] = bm * g3[i] + t2[i]; }
     }
-    for (int i = 0; i < 6; i++)
-      kv[i] = hb[i] + qo.legs_sum(hbN[i] + (ct ? (X[3 * i] * bc[0] + X[3 * i + 1] * bc[1] + X[3 * i + 2] * bc[2]) : 0.0));
-    const double Mc = bm + qo.legs_sum(lm);
-    double Hc[3], Ic[6];
-    for (int i = 0; i < 3; i++) Hc[i] = bmc[i] + qo.legs_sum(lh[i]);
-    for (int i = 0; i < 6; i++) Ic[i] = bI[i] + qo.legs_sum(lI[i]);
+    // every sum over the legs of this phase in two batches (leg-level values are replicated on the sub-lanes: legs_sum_n)
+    double Hc[3], Ic[6], Mc;
+    {
+      double t[16];
+      for (int i = 0; i < 6; i++) t[i] = hbN[i] + (ct ? (X[3 * i] * bc[0] + X[3 * i + 1] * bc[1] + X[3 * i + 2] * bc[2]) : 0.0);
+      t[6] = lm;
+      for (int i = 0; i < 3; i++) t[7 + i] = lh[i];
+      for (int i = 0; i < 6; i++) t[10 + i] = lI[i];
+      qo.template legs_sum_n<16>(t);
+      for (int i = 0; i < 6; i++) kv[i] = hb[i] + t[i];
+      Mc = bm + t[6];
+      for (int i = 0; i < 3; i++) Hc[i] = bmc[i] + t[7 + i];
+      for (int i = 0; i < 6; i++) Ic[i] = bI[i] + t[10 + i];
+    }
     double Mbb[6][6];
     for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) Mbb[i][j] = 0.0;
     Mbb[0][0] = Ic[0]; Mbb[1][1] = Ic[1]; Mbb[2][2] = Ic[2];
@@ -900,14 +917,20 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     Mbb[2][3] = -Hc[1]; Mbb[2][4] = Hc[0];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Mbb[3 + j][i] = Mbb[i][3 + j];
     Mbb[3][3] = Mc; Mbb[4][4] = Mc; Mbb[5][5] = Mc;
-    for (int i = 0; i < 6; i++) {
-      const double a0 = X[3 * i], a1 = X[3 * i + 1], a2 = X[3 * i + 2];
-      Gs[i][0] = Mbb[i][0] + qo.legs_sum(a1 * rf[2] - a2 * rf[1]);
-      Gs[i][1] = Mbb[i][1] + qo.legs_sum(a2 * rf[0] - a0 * rf[2]);
-      Gs[i][2] = Mbb[i][2] + qo.legs_sum(a0 * rf[1] - a1 * rf[0]);
-      Gs[i][3] = Mbb[i][3] - qo.legs_sum(a0);
-      Gs[i][4] = Mbb[i][4] - qo.legs_sum(a1);
-      Gs[i][5] = Mbb[i][5] - qo.legs_sum(a2);
+    {
+      double g[36];
+      for (int i = 0; i < 6; i++) {
+        const double a0 = X[3 * i], a1 = X[3 * i + 1], a2 = X[3 * i + 2];
+        g[6 * i + 0] = a1 * rf[2] - a2 * rf[1];
+        g[6 * i + 1] = a2 * rf[0] - a0 * rf[2];
+        g[6 * i + 2] = a0 * rf[1] - a1 * rf[0];
+        g[6 * i + 3] = -a0;
+        g[6 * i + 4] = -a1;
+        g[6 * i + 5] = -a2;
+      }
+      qo.template legs_sum_n<36>(g);
+      for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) Gs[i][j] = Mbb[i][j] + g[6 * i + j];
     }
     if (MP)
       for (int i = 0; i < 6; i++)
@@ -966,22 +989,29 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   };
   // level-2 rows eps (T z + t0):  T[(l',i)][(l,j)] = Y_l'[i] . B_l[:,j] + delta D_l[i][j].  (Folding them into
   // the level-1 append -- one pass of 12 pivots over 30 rows -- was measured: it spills, profiles/r02.)
+  // [B_col | 1 on the right-hand-side lanes]: the rows' constants (t0, c1) ride along as a seventh term of the all-pairs blocks
+  double bcol7[7];
+  for (int k = 0; k < 6; k++) bcol7[k] = bcol[k];
+  bcol7[6] = colv ? 0.0 : 1.0;
   auto level2_rows = [&](double* A2) {
-    qo.template dpp_fence<6>(Yrow);
+    double Y7[7];
+    for (int k = 0; k < 6; k++) Y7[k] = Yrow[k];
+    Y7[6] = t0_own;
+    qo.template dpp_fence<7>(Y7);
+    const double se = colv ? eps : (cold ? 0.0 : -eps);   // the right-hand side carries the opposite sign
     static_for<NZ / 3>([&](auto RR) {
       // three rows at a time, their fused chains interleaved (an inline-asm result is not read for two instructions)
       constexpr int r0 = 3 * RR, r1 = r0 + 1, r2 = r0 + 2;
       constexpr int s0 = hex_lane(r0), s1 = hex_lane(r1), s2 = hex_lane(r2);
       // column lanes: D_l entry + Y_row . B_col ;  rhs lanes: t0_row + Y_row . ab0   (one fused broadcast-FMA per term)
-      const double t0a = qo.bcast16(t0_own, s0), t0b = qo.bcast16(t0_own, s1), t0c = qo.bcast16(t0_own, s2);
-      const bool own = (r0 / 3 == l);   // rows r0..r2 belong to leg RR
-      double da = colv ? (own ? Dcol[0] : 0.0) : t0a;
-      double db = colv ? (own ? Dcol[1] : 0.0) : t0b;
-      double dc = colv ? (own ? Dcol[2] : 0.0) : t0c;
-      qo.template rows3_bc<s0, s1, s2>(da, db, dc, Yrow, bcol);
-      A2[r0] = colv ? eps * da : (cold ? 0.0 : -eps * da);
-      A2[r1] = colv ? eps * db : (cold ? 0.0 : -eps * db);
-      A2[r2] = colv ? eps * dc : (cold ? 0.0 : -eps * dc);
+      const bool own = colv && (r0 / 3 == l);   // rows r0..r2 belong to leg RR
+      double da = own ? Dcol[0] : 0.0;
+      double db = own ? Dcol[1] : 0.0;
+      double dc = own ? Dcol[2] : 0.0;
+      qo.template rows3_bc7<s0, s1, s2>(da, db, dc, Y7, bcol7);
+      A2[r0] = se * da;
+      A2[r1] = se * db;
+      A2[r2] = se * dc;
     });
   };
   // Level-1 rows (P1 of them) and the 12 level-2 rows are folded in ONE append of P1 + 12 rows: 12 pivot steps
@@ -1060,10 +1090,14 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       double gl[3], c[3];
       for (int i = 0; i < 3; i++) gl[i] = Ji[i] * Cl[0] + Ji[3 + i] * Cl[1] + Ji[6 + i] * Cl[2];
       cross(rf, gl, c);
-      for (int j = 0; j < 6; j++) {
-        double loc = Cb_leg[j] - ((j < 3) ? c[j] : gl[j - 3]);
-        if (ct) loc -= MiY[j] * Cl[0] + MiY[6 + j] * Cl[1] + MiY[12 + j] * Cl[2];
-        LJ_b[j] = Cb_base[j] + qo.legs_sum(loc);
+      {
+        double loc[6];
+        for (int j = 0; j < 6; j++) {
+          loc[j] = Cb_leg[j] - ((j < 3) ? c[j] : gl[j - 3]);
+          if (ct) loc[j] -= MiY[j] * Cl[0] + MiY[6 + j] * Cl[1] + MiY[12 + j] * Cl[2];
+        }
+        qo.template legs_sum_n<6>(loc);
+        for (int j = 0; j < 6; j++) LJ_b[j] = Cb_base[j] + loc[j];
       }
       for (int i = 0; i < 3; i++) LJ_s[i] = ct ? 0.0 : gl[i];
     }
@@ -1089,8 +1123,10 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
         lv += 0.5 * P.Kp_foot * xt_s[i] * xt_s[i] + 0.5 * xdt_s[i] * Lx_s[i];
         lvd += -P.Kd_foot * xdt_s[i] * xdt_s[i] + xdt_s[i] * c1_s[i];
       }
-      met_V += qo.legs_sum(lv);
-      met_Vdot += qo.legs_sum(lvd);
+      double lvs[2] = {lv, lvd};
+      qo.template legs_sum_n<2>(lvs);
+      met_V += lvs[0];
+      met_Vdot += lvs[1];
     }
     {
       // (Ji Jfb)' Y = [ rf x M ; M ] with M = Ji' Y (= Mt_bl, already formed): column j of the top block is rf x M[:, j]
@@ -1098,31 +1134,46 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       vrow_own = (colv && !ct) ? pick3(sb, Lx_s[0], Lx_s[1], Lx_s[2]) : 0.0;
       // Lambda_bb = G_b - sum_l C_l is symmetric (a task-space inertia): only the upper triangle is formed
       // (21 instead of 36 leg sums), the lower one is mirrored from the rows already done
+      // the 21 + 12 leg sums of this block in one batch
       double Lup[6][6];
+      {
+        double cs[33];
+        int e = 0;
 #pragma unroll
-      for (int i = 0; i < 6; i++) {
-        double Lrow[6];
+        for (int i = 0; i < 6; i++) {
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-          if (j < i) { Lrow[j] = Lup[j][i]; continue; }
-          const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
-          double c = (i < 3) ? rf[i1] * Mt_bl[3 * j + i2] - rf[i2] * Mt_bl[3 * j + i1] : Mt_bl[3 * j + (i - 3)];
-          if (ct) c += Y[i] * MiY[j] + Y[6 + i] * MiY[6 + j] + Y[12 + i] * MiY[12 + j];
-          Lrow[j] = pk.get(PK_GS + 6 * i + j) - qo.legs_sum(c);
-          Lup[i][j] = Lrow[j];
+          for (int j = i; j < 6; j++) {
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+            double c = (i < 3) ? rf[i1] * Mt_bl[3 * j + i2] - rf[i2] * Mt_bl[3 * j + i1] : Mt_bl[3 * j + (i - 3)];
+            if (ct) c += Y[i] * MiY[j] + Y[6 + i] * MiY[6 + j] + Y[12 + i] * MiY[12 + j];
+            cs[e++] = c;
+          }
         }
-        double ls = 0.0, lx = 0.0, lb = 0.0;
 #pragma unroll
-        for (int j = 0; j < 6; j++) { ls += Lrow[j] * xdd_b[j]; lx += Lrow[j] * xdt_b[j]; lb += Lrow[j] * bcol[j]; }
-        ls += qo.legs_sum(ct ? 0.0 : Mt_bl[3 * i] * s1_s[0] + Mt_bl[3 * i + 1] * s1_s[1] + Mt_bl[3 * i + 2] * s1_s[2]);
-        lx += qo.legs_sum(ct ? 0.0 : Mt_bl[3 * i] * xdt_s[0] + Mt_bl[3 * i + 1] * xdt_s[1] + Mt_bl[3 * i + 2] * xdt_s[2]);
-        const double kp = (i < 3) ? P.Kp_body_rpy : P.Kp_body_p, kd = (i < 3) ? P.Kd_body_rpy : P.Kd_body_p;
-        const double c1 = LJ_b[i] - ls + kp * xt_b[i] + kd * xdt_b[i];
-        met_V += 0.5 * kp * xt_b[i] * xt_b[i] + 0.5 * xdt_b[i] * lx;
-        met_Vdot += -kd * xdt_b[i] * xdt_b[i] + xdt_b[i] * c1;
-        vrow_own += lx * bcol[i];
-        const double sw_term = ct ? 0.0 : pick3(sb, Mt_bl[3 * i], Mt_bl[3 * i + 1], Mt_bl[3 * i + 2]);
-        Acol[i] = colv ? sw_b * (lb + sw_term) : -sw_b * (c1 + lb);
+        for (int i = 0; i < 6; i++) {
+          cs[21 + i] = ct ? 0.0 : Mt_bl[3 * i] * s1_s[0] + Mt_bl[3 * i + 1] * s1_s[1] + Mt_bl[3 * i + 2] * s1_s[2];
+          cs[27 + i] = ct ? 0.0 : Mt_bl[3 * i] * xdt_s[0] + Mt_bl[3 * i + 1] * xdt_s[1] + Mt_bl[3 * i + 2] * xdt_s[2];
+        }
+        qo.template legs_sum_n<33>(cs);
+        e = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+          for (int j = i; j < 6; j++) { Lup[i][j] = pk.get(PK_GS + 6 * i + j) - cs[e++]; Lup[j][i] = Lup[i][j]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          double ls = cs[21 + i], lx = cs[27 + i], lb = 0.0;
+#pragma unroll
+          for (int j = 0; j < 6; j++) { ls += Lup[i][j] * xdd_b[j]; lx += Lup[i][j] * xdt_b[j]; lb += Lup[i][j] * bcol[j]; }
+          const double kp = (i < 3) ? P.Kp_body_rpy : P.Kp_body_p, kd = (i < 3) ? P.Kd_body_rpy : P.Kd_body_p;
+          const double c1 = LJ_b[i] - ls + kp * xt_b[i] + kd * xdt_b[i];
+          met_V += 0.5 * kp * xt_b[i] * xt_b[i] + 0.5 * xdt_b[i] * lx;
+          met_Vdot += -kd * xdt_b[i] * xdt_b[i] + xdt_b[i] * c1;
+          vrow_own += lx * bcol[i];
+          const double sw_term = ct ? 0.0 : pick3(sb, Mt_bl[3 * i], Mt_bl[3 * i + 1], Mt_bl[3 * i + 2]);
+          Acol[i] = colv ? sw_b * (lb + sw_term) : -sw_b * (c1 + lb);
+        }
       }
       vconst = qo.leg_bcast(vrow_own, 3);
     }
@@ -1132,21 +1183,23 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       double Msb[6], Msc[3];   // Msc[i] = Lambda_ss[i][sub]: own column of the leg's swing block
       for (int k = 0; k < 6; k++) Msb[k] = ct ? 0.0 : pick3(sb, Mt_bl[3 * k], Mt_bl[3 * k + 1], Mt_bl[3 * k + 2]);
       for (int i = 0; i < 3; i++) Msc[i] = ct ? 0.0 : pick3(sb, Mt_ll[3 * i], Mt_ll[3 * i + 1], Mt_ll[3 * i + 2]);
-      const double c1o = ct ? 0.0 : pick3(sb, c1_s[0], c1_s[1], c1_s[2]);
-      qo.template dpp_fence<6>(Msb);
+      double Msb7[7];
+      for (int k = 0; k < 6; k++) Msb7[k] = Msb[k];
+      Msb7[6] = ct ? 0.0 : pick3(sb, c1_s[0], c1_s[1], c1_s[2]);
+      qo.template dpp_fence<7>(Msb7);
+      const double sf = colv ? sw_f : -sw_f;
       static_for<NZ / 3>([&](auto RR) {
         constexpr int r0 = 3 * RR, r1 = r0 + 1, r2 = r0 + 2;
         constexpr int s0 = hex_lane(r0), s1 = hex_lane(r1), s2 = hex_lane(r2);
         // column lanes: Lambda_ss entry (row r, own column; own leg only) + Lambda_sb row . B_col ;  rhs lanes: c1_row + Lambda_sb row . ab0
-        const double c1a = qo.bcast16(c1o, s0), c1b = qo.bcast16(c1o, s1), c1c = qo.bcast16(c1o, s2);
-        const bool own = (r0 / 3 == l);
-        double da = colv ? (own ? Msc[0] : 0.0) : c1a;
-        double db = colv ? (own ? Msc[1] : 0.0) : c1b;
-        double dc = colv ? (own ? Msc[2] : 0.0) : c1c;
-        qo.template rows3_bc<s0, s1, s2>(da, db, dc, Msb, bcol);
-        Acol[6 + r0] = colv ? sw_f * da : -sw_f * da;
-        Acol[6 + r1] = colv ? sw_f * db : -sw_f * db;
-        Acol[6 + r2] = colv ? sw_f * dc : -sw_f * dc;
+        const bool own = colv && (r0 / 3 == l);
+        double da = own ? Msc[0] : 0.0;
+        double db = own ? Msc[1] : 0.0;
+        double dc = own ? Msc[2] : 0.0;
+        qo.template rows3_bc7<s0, s1, s2>(da, db, dc, Msb7, bcol7);
+        Acol[6 + r0] = sf * da;
+        Acol[6 + r1] = sf * db;
+        Acol[6 + r2] = sf * dc;
       });
     }
     init_rcol();

@@ -148,6 +148,14 @@ struct HexDev {
                  : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]),
                    [l0] "n"(L0), [l1] "n"(L1), [l2] "n"(L2));
   }
+  // the same with a seventh term (the rows' constant rides along: x[6] = the row's constant, y[6] = 1 on the right-hand-side
+  // lanes and 0 on the column lanes -- no separate broadcast + select of the constant)
+  template <int L0, int L1, int L2> __device__ __forceinline__ void rows3_bc7(double& d0, double& d1, double& d2, const double* x, const double* y) const {
+    asm volatile(WBC_FP(0, 3, 10, l0) WBC_FP(1, 3, 10, l1) WBC_FP(2, 3, 10, l2) WBC_FP(0, 4, 11, l0) WBC_FP(1, 4, 11, l1) WBC_FP(2, 4, 11, l2) WBC_FP(0, 5, 12, l0) WBC_FP(1, 5, 12, l1) WBC_FP(2, 5, 12, l2) WBC_FP(0, 6, 13, l0) WBC_FP(1, 6, 13, l1) WBC_FP(2, 6, 13, l2) WBC_FP(0, 7, 14, l0) WBC_FP(1, 7, 14, l1) WBC_FP(2, 7, 14, l2) WBC_FP(0, 8, 15, l0) WBC_FP(1, 8, 15, l1) WBC_FP(2, 8, 15, l2) WBC_FP(0, 9, 16, l0) WBC_FP(1, 9, 16, l1) WBC_FP(2, 9, 16, l2)
+                 : "+v"(d0), "+v"(d1), "+v"(d2)
+                 : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]),
+                   [l0] "n"(L0), [l1] "n"(L1), [l2] "n"(L2));
+  }
 #undef WBC_FP
   // s_nop 4 = 5 wait states: covers the DPP-source rule (2) and "VALU wrote EXEC" (5)
   template <int N> static __device__ __forceinline__ void dpp_fence(double* a) {
@@ -183,6 +191,24 @@ struct HexDev {
     return x;
   }
   __device__ __forceinline__ double sum16(double x) const { return legs_sum(leg_sum(x)); }
+  // Sum over the four legs of N values that are REPLICATED on the four sub-lanes of their leg, result on all 16 lanes:
+  // ((x[lane 0] + x[lane 4]) + x[lane 8]) + x[lane 12] as one v_mov_b64_dpp + three fused broadcast-FMAs with 1.0 (4
+  // instructions instead of the 6 of the row_ror butterfly; the DP ALU takes no other DPP control).  One hazard fence
+  // for the whole batch, the N chains are independent.
+  template <int N> __device__ __forceinline__ void legs_sum_n(double* x) const {
+    dpp_fence<N>(x);
+    const double one = 1.0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      double acc;
+      asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_fmac_f64_dpp %0, %1, %2 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_fmac_f64_dpp %0, %1, %2 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                   "v_fmac_f64_dpp %0, %1, %2 row_newbcast:12 row_mask:0xf bank_mask:0xf"
+                   : "=&v"(acc) : "v"(x[i]), "v"(one));
+      x[i] = acc;
+    }
+  }
   // v_min_f64 / v_max_f64 through asm: fmin()/fmax() first canonicalise both operands (a v_max_f64 x, x, x each), which
   // only matters for signalling NaNs -- the keys here are never NaN (HEX_NONE is finite)
   static __device__ __forceinline__ double vmin(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }

@@ -196,6 +196,9 @@ struct HexHost {
   template <int L0, int L1, int L2> void rows3_bc(double& d0, double& d1, double& d2, const double* x, const double* y) {
     for (int k = 0; k < 6; k++) { d0 += xchg(x[k], L0) * y[k]; d1 += xchg(x[k], L1) * y[k]; d2 += xchg(x[k], L2) * y[k]; }
   }
+  template <int L0, int L1, int L2> void rows3_bc7(double& d0, double& d1, double& d2, const double* x, const double* y) {
+    for (int k = 0; k < 7; k++) { d0 += xchg(x[k], L0) * y[k]; d1 += xchg(x[k], L1) * y[k]; d2 += xchg(x[k], L2) * y[k]; }
+  }
   double leg_bcast(double x, int s0) { return xchg(x, (h & ~3) | s0); }
   double leg_pairs(double x) { return xchg(x, (h & ~3) | ((h & 3) >> 1)); }   // quad_perm [0,0,1,1]
   double bcast16d(double x, int src) { return xchg(x, src); }                  // dynamic (robot-uniform) source lane
@@ -215,6 +218,14 @@ struct HexHost {
     const double* s = g_hex->slot;
     const double r = (s[h] + s[h ^ 8]) + (s[h ^ 4] + s[h ^ 12]); hex_barrier(h);
     return r;
+  }
+  template <int N> void legs_sum_n(double* x) {   // device: v_mov_b64_dpp + 3 fused broadcast-FMAs per value (sub-lane 0 of each leg)
+    for (int i = 0; i < N; i++) {
+      g_hex->slot[h] = x[i]; hex_barrier(h);
+      const double* s = g_hex->slot;
+      const double r = ((s[0] + s[4]) + s[8]) + s[12]; hex_barrier(h);
+      x[i] = r;
+    }
   }
   double sum16(double x) {
     g_hex->slot[h] = x; hex_barrier(h);
