@@ -17,6 +17,8 @@ for w in mptc3 id2 pc3 clf3 id3 anymal4 rand5 rand5_32768 tb_mptc3 rollout_mptc 
   ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $root/$out/all/$w -o run --output-format csv -- python3 $root/tools/all_kernels.py $w $root/$out/all > $root/$out/all/$w.log 2>&1 )
 done
 python3 tools/all_kernels.py --report $out/all > $out/all_kernels.md 2> $out/all_kernels.err
+# the per-launch traces are tens of MB each (gpurun copies back <= 64 MiB): keep the profiler's summaries only
+find $out -name "*kernel_trace.csv" -delete; find $out -name "*.db" -delete; find $out -name "*domain_stats.csv" -delete
 G1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES"
 G2="SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM"
 G3="SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"
