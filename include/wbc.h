@@ -60,7 +60,9 @@ extern "C" {
 
 /* wbc_create flags */
 #define WBC_DEVICE_PTRS 0u /* wbc_step receives device pointers (default) */
-#define WBC_HOST_PTRS 1u   /* wbc_step receives host pointers; staged through handle-owned buffers */
+#define WBC_HOST_PTRS 1u   /* wbc_step receives host pointers; staged through handle-owned buffers (n <= 64: one pinned,
+                              device-mapped block the kernel reads and writes directly, no copy calls).  As with device
+                              pointers the outputs are valid after wbc_sync (a later wbc_step on the handle collects them too) */
 
 /* Kinematic tree + inertias, as produced by tools/compile_model.py from the reference's URDFs
  * (models/mini_cheetah/mini_cheetah_mesh.urdf, models/anymal_b_simple_description/urdf/anymal_drake.urdf):

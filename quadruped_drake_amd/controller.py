@@ -297,6 +297,7 @@ class BatchedController:
         qq = np.asarray(q, float).reshape(19, 1); vv = np.asarray(v, float).reshape(18, 1)
         if self.host_ptrs:
             tau, met, st = self.step(qq, vv, t.reshape(54, 1), np.array([mask], np.uint8))
+            self.sync()                       # the ABI hands the outputs over at wbc_sync
             tau, met, st = tau[:, 0], met[:, 0], int(st[0])
         else:
             import torch

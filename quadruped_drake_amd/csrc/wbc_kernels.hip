@@ -613,7 +613,29 @@ struct wbc_handle_s {
   double *s_q, *s_v, *s_tg, *s_mu, *s_ms, *s_tau, *s_met;
   uint8_t* s_mask;
   int32_t* s_status;
+  // WBC_HOST_PTRS, small batches (n <= ZC_MAX: the LeafSystem adapter's one robot): ONE pinned, device-mapped block.  The tick reads
+  // its inputs and writes its outputs straight through it (728 + 132 bytes per robot over PCIe inside the kernel): no copy calls at
+  // all -- each of the nine hipMemcpy*Async calls of the staged path costs the host ~10 us, the kernel itself ~15 us.  The outputs
+  // reach the caller's arrays in wbc_sync (or at the next wbc_step), which is when the ABI promises them.
+  double* z_host;
+  double* z_dev;
+  struct { bool active; int n, ld; double* tau; double* met; int32_t* status; } zpend;
 };
+constexpr int ZC_MAX = 64;
+// block layout, in doubles, leading dimension n: q 19 | v 18 | targets 54 | mu | mass scale | tau 12 | metrics 4 ; then at fixed offsets status (int32) and mask (bytes)
+constexpr size_t ZC_STATUS_OFF = 109 * ZC_MAX, ZC_MASK_OFF = ZC_STATUS_OFF + ZC_MAX / 2, ZC_DOUBLES = ZC_MASK_OFF + ZC_MAX / 8;
+
+static int zc_finish(wbc_handle_s* h) {   // the pending small-batch tick: wait, hand the outputs over
+  if (!h->zpend.active) return 0;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const int n = h->zpend.n, ld = h->zpend.ld;
+  const double* z = h->z_host;
+  for (int r = 0; r < 12; r++) memcpy(h->zpend.tau + (size_t)r * ld, z + (size_t)(93 + r) * n, (size_t)n * 8);
+  if (h->zpend.met) for (int r = 0; r < 4; r++) memcpy(h->zpend.met + (size_t)r * ld, z + (size_t)(105 + r) * n, (size_t)n * 8);
+  if (h->zpend.status) memcpy(h->zpend.status, z + ZC_STATUS_OFF, (size_t)n * 4);
+  h->zpend.active = false;
+  return 0;
+}
 
 extern "C" int wbc_traj_raw_(wbc_traj t, wbc::TrajDev* out);   // wbc_traj.hip (internal)
 // internal: wbc_traj.hip reports its failures through the same thread-local buffer wbc_last_error() returns
@@ -689,6 +711,8 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
       HIP_TRY(hipMalloc(&h->s_ms, nb * 8)); HIP_TRY(hipMalloc(&h->s_tau, 12 * nb * 8));
       HIP_TRY(hipMalloc(&h->s_met, 4 * nb * 8)); HIP_TRY(hipMalloc(&h->s_mask, nb));
       HIP_TRY(hipMalloc(&h->s_status, nb * 4));
+      HIP_TRY(hipHostMalloc(&h->z_host, ZC_DOUBLES * 8, hipHostMallocMapped));
+      HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h->z_dev), h->z_host, 0));
     }
     return 0;
   };
@@ -706,6 +730,7 @@ int wbc_destroy(wbc_handle h) {
                   h->s_tau, h->s_met, h->s_mask, h->s_status};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (h->h_stats) (void)hipHostFree(h->h_stats);
+  if (h->z_host) (void)hipHostFree(h->z_host);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (hipEvent_t e : h->evs) (void)hipEventDestroy(e);
@@ -782,6 +807,25 @@ int wbc_step(wbc_handle h, int n, int ld, const double* q, const double* v, cons
   HIP_TRY(hipSetDevice(h->device));
   if (!(h->flags & WBC_HOST_PTRS))
     return launch(h, n, ld, q, v, targets, contact_mask, mu, mass_scale, tau, metrics, status);
+  rc = zc_finish(h);                    // a small-batch tick whose outputs were never collected: collect them first
+  if (rc) return rc;
+  if (n <= ZC_MAX) {
+    // small batch: inputs written into the mapped block, the kernel works through it, outputs handed over at wbc_sync
+    double* z = h->z_host;
+    for (int r = 0; r < 19; r++) memcpy(z + (size_t)r * n, q + (size_t)r * ld, (size_t)n * 8);
+    for (int r = 0; r < 18; r++) memcpy(z + (size_t)(19 + r) * n, v + (size_t)r * ld, (size_t)n * 8);
+    for (int r = 0; r < 54; r++) memcpy(z + (size_t)(37 + r) * n, targets + (size_t)r * ld, (size_t)n * 8);
+    if (mu) memcpy(z + (size_t)91 * n, mu, (size_t)n * 8);
+    if (mass_scale) memcpy(z + (size_t)92 * n, mass_scale, (size_t)n * 8);
+    memcpy(z + ZC_MASK_OFF, contact_mask, (size_t)n);
+    double* d = h->z_dev;
+    rc = launch(h, n, n, d, d + (size_t)19 * n, d + (size_t)37 * n, reinterpret_cast<const uint8_t*>(d + ZC_MASK_OFF),
+                mu ? d + (size_t)91 * n : nullptr, mass_scale ? d + (size_t)92 * n : nullptr, d + (size_t)93 * n,
+                metrics ? d + (size_t)105 * n : nullptr, status ? reinterpret_cast<int32_t*>(d + ZC_STATUS_OFF) : nullptr);
+    if (rc) return rc;
+    h->zpend = {true, n, ld, tau, metrics, status};
+    return 0;
+  }
   // host pointers: stage rows through the handle's device buffers (leading dimension n on the device)
   hipStream_t s = h->stream;
   HIP_TRY(hipMemcpy2DAsync(h->s_q, (size_t)n * 8, q, (size_t)ld * 8, (size_t)n * 8, 19, hipMemcpyHostToDevice, s));
@@ -803,7 +847,7 @@ int wbc_sync(wbc_handle h) {
   if (!h) return misuse("wbc_sync: null handle");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  return 0;
+  return zc_finish(h);
 }
 
 int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, const double* v,

@@ -153,6 +153,41 @@ def test_torque_box_friction_and_host_pointer_mode():
     assert rel_err(tau[:, ok], tau_o[:, ok]).max() < TOL
 
 
+def test_host_pointer_small_batch_goes_through_the_mapped_block():
+    """WBC_HOST_PTRS with n <= 64 (the LeafSystem adapter's one robot): the tick reads and writes ONE pinned, device-mapped block,
+    no copy calls; outputs are handed over at wbc_sync.  Same bits as the device-pointer path; a sub-batch with ld > n, per-instance
+    mu / mass scale, two steps before one sync (the second collects the first), n = 1 and n = 64."""
+    torch = _torch()
+    import ctypes as C
+    from quadruped_drake_amd import MPTCController, _lib, workloads
+    b = workloads.make_batch(5, n=64)
+    dev = MPTCController(model=b["model"], max_batch=64, device=0)
+    up = lambda x: torch.tensor(x, device="cuda:0")
+    tau_d, met_d, st_d = dev.step(up(b["q"]), up(b["v"]), up(b["targets"]), up(b["mask"]), up(b["mu"]), up(b["mass_scale"])); dev.sync()
+    tau_d, met_d, st_d = tau_d.cpu().numpy(), met_d.cpu().numpy(), st_d.cpu().numpy()
+    dev.close()
+    host = MPTCController(model=b["model"], max_batch=64, device=0, host_ptrs=True)
+    for n in (1, 5, 64):
+        tau, met, st = host.step(b["q"][:, :n], b["v"][:, :n], b["targets"][:, :n], b["mask"][:n], b["mu"][:n], b["mass_scale"][:n])
+        assert np.array_equal(tau, tau_d[:, :n]) and np.array_equal(met, met_d[:, :n]) and np.array_equal(st, st_d[:n])
+    # raw ABI: ld > n, two steps, one sync
+    L = _lib.lib()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    q, v, tg = (np.ascontiguousarray(b[k]) for k in ("q", "v", "targets"))      # ld = 64
+    t1 = np.zeros((12, 64)); t2 = np.zeros((12, 56)); m2 = np.zeros((4, 56)); s2 = np.full(56, -1, np.int32)   # ld applies to every array of a call
+    n = 7
+    _lib.check(L.wbc_step(host._h, n, 64, p(q), p(v), p(tg), p(b["mask"]), p(b["mu"]), p(b["mass_scale"]), p(t1), None, None))
+    q2, v2, tg2 = (np.ascontiguousarray(b[k][:, 8:]) for k in ("q", "v", "targets"))    # another sub-batch, ld = 56
+    _lib.check(L.wbc_step(host._h, n, 56, p(q2), p(v2), p(tg2), p(np.ascontiguousarray(b["mask"][8:])), p(np.ascontiguousarray(b["mu"][8:])),
+                          p(np.ascontiguousarray(b["mass_scale"][8:])), p(t2), p(m2), p(s2)))
+    assert np.array_equal(t1[:, :n], tau_d[:, :n]) and (t1[:, n:] == 0).all()      # collected when the second step started
+    assert (t2 == 0).all()                                                         # not yet: the ABI hands outputs over at wbc_sync
+    host.sync()
+    assert np.array_equal(t2[:, :n], tau_d[:, 8:8 + n]) and np.array_equal(m2[:, :n], met_d[:, 8:8 + n]) and np.array_equal(s2[:n], st_d[8:8 + n])
+    assert (t2[:, n:] == 0).all() and (s2[n:] == -1).all()
+    host.close()
+
+
 @pytest.mark.parametrize("cfg,kind,tmax", [(3, "mptc", 10.0), (2, "id", 12.0), (3, "clf", 12.0), (3, "pc", 10.0)])
 def test_torque_box(cfg, kind, tmax):
     """tau_max < inf: 24 more inequality rows (north star: torque-limit inequalities); device pointers, N = 512."""
