@@ -237,11 +237,15 @@ struct HexDev {
   }
   __device__ __forceinline__ bool wave_all(bool b) const { return __all(b); }
   __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }
-  __device__ __forceinline__ int wave_max_int(int x) const {
+  __device__ __forceinline__ int wave_max_int(int x) const {   // maximum over the wavefront of a value in 0..15, wave-uniform
     int m = 0;
+    bool cand = true;        // lanes whose value still agrees with the maximum's leading bits
 #pragma unroll
-    for (int b = 0; b < 4; b++) m |= (__any((x >> b) & 1) ? 1 : 0) << b;
-    return m;
+    for (int b = 3; b >= 0; b--) {
+      const bool bit = (x >> b) & 1;
+      if (__any(cand && bit)) { m |= 1 << b; cand = cand && bit; }
+    }
+    return __builtin_amdgcn_readfirstlane(m);
   }
 };
 
@@ -741,6 +745,10 @@ int wbc_destroy(wbc_handle h) {
 
 int wbc_set_stream(wbc_handle h, void* hip_stream) {
   if (!h) return misuse("wbc_set_stream: null handle");
+  if (h->zpend.active) {                 // a small-batch host-pointer tick still in flight on the old stream: collect it first
+    const int rc = zc_finish(h);
+    if (rc) return rc;
+  }
   if (h->own_stream) {
     (void)hipStreamSynchronize(h->stream);
     (void)hipStreamDestroy(h->stream);

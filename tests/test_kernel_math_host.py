@@ -208,3 +208,34 @@ def test_fast_and_generic_paths_round_identically():
                 assert np.array_equal(r[0], ref[0]) and np.array_equal(r[1], ref[1]) and np.array_equal(r[3], ref[3]), (kind, k)
         finally:
             L.host_gi_force_bail(-1)
+
+
+def test_givens_drop_build_option_on_host(tmp_path):
+    """-DWBC_GIVENS_DROPS=1 (the task-space laws drop by Givens rotations computed from the images instead of the W-row
+    reflection: csrc/wbc_hex.hpp) is a build option; its code path is kept alive here on the drop-heavy 4-contact stand."""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libhost_tick_givens.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", "-DWBC_GIVENS_DROPS=1",
+                           "-o", so, os.path.join(root, "tools", "host_tick.cpp")])
+    L = C.CDLL(so)
+    b = workloads.make_batch(2, n=96)
+    t = orc.load_model_json(b["model"])
+    dp = C.POINTER(C.c_double)
+    for kind, k in (("mptc", 1), ("pc", 2)):
+        n = 96
+        q, v, tg = (np.ascontiguousarray(b[x]) for x in ("q", "v", "targets"))
+        flat = np.ascontiguousarray(t["flat"], dtype=np.float64)
+        tau = np.zeros((12, n)); met = np.zeros((4, n)); st = np.zeros(n, np.int32); it = np.zeros(n, np.int32)
+        rc = L.host_hex_batch(k, flat.ctypes.data_as(dp), None, None, None, n, n, q.ctypes.data_as(dp), v.ctypes.data_as(dp),
+                              tg.ctypes.data_as(dp), b["mask"].ctypes.data_as(C.POINTER(C.c_ubyte)), None, None,
+                              tau.ctypes.data_as(dp), met.ctypes.data_as(dp), st.ctypes.data_as(C.POINTER(C.c_int)),
+                              it.ctypes.data_as(C.POINTER(C.c_int)))
+        assert rc == 0
+        stats = np.zeros(3, np.int32)
+        L.host_gi_stats(stats.ctypes.data_as(C.POINTER(C.c_int)), 1)
+        tau_o, met_o, st_o = orc.step_batch(kind, orc.model(b["model"]), orc.params(kind), b["q"], b["v"], b["targets"], b["mask"])
+        assert (st == 0).all() and (st_o == 0).all() and stats[2] > 50          # plenty of drops went through the rotations
+        assert rel_err(tau, tau_o).max() < 1e-5

@@ -5,6 +5,7 @@
 //     bench.py's roofline uses.
 // The shipped library (libwbc_hip.so) never calls this; it has no CPU path.
 #include <math.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include <string.h>
 #include "../quadruped_drake_amd/csrc/wbc_model.hpp"
@@ -265,7 +266,7 @@ struct HexHost {
     v = bv; i = bi;
   }
   bool wave_all(bool b) { return b; }
-  bool wave_any(bool b) { return b; }
+  bool wave_any(bool b) { return getenv("WBC_ANY_TRUE") ? true : b; }
   int wave_max_int(int x) { return x; }
 };
 

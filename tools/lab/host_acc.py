@@ -8,7 +8,7 @@ from quadruped_drake_amd import workloads
 from oracle import oracle_py as orc
 cfg = int(sys.argv[1]); n = int(sys.argv[2]); kind = sys.argv[3]; seed = int(sys.argv[4]) if len(sys.argv) > 4 else None
 prm = {}
-if len(sys.argv) > 5: prm = {"tau_max": float(sys.argv[5])}
+if len(sys.argv) > 5 and sys.argv[5]: prm = {"tau_max": float(sys.argv[5])}
 b = workloads.make_batch(cfg, n=n, seed=seed)
 t = orc.load_model_json(b["model"])
 p = orc.params(kind)
@@ -26,3 +26,7 @@ r = np.abs(tau[:, ok] - tau_o[:, ok]).max(0) / np.maximum(np.abs(tau_o[:, ok]).m
 print("%s cfg %d n %d: status mismatches %d, rel err median %.2e p99 %.2e max %.2e | iters mean %.2f max %d wave4 mean %.2f | fast/generic/drops %s" % (
     kind, cfg, n, ((st == 0) != (st_o == 0)).sum(), np.median(r), np.percentile(r, 99), r.max(), it.mean(), it.max(),
     it[: n // 4 * 4].reshape(-1, 4).max(1).mean(), st3))
+idx = np.argsort(-r)[:8]
+print("worst robots:", [(int(np.where(ok)[0][i]), "%.1e" % r[i], int(it[np.where(ok)[0][i]])) for i in idx])
+if len(sys.argv) > 6:
+    np.save(sys.argv[6], r)
