@@ -280,7 +280,9 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         t1 = have_t1 ? key : INF;
       }
       const bool dependent = !(d2n > 1e-22 * dnx);
-      const double t2 = -spx * fast_rcp(d2n);
+      double nrm, rsn;                                   // |d[qc:]| and its reciprocal from one seed: step length, norm and 1/alpha
+      fast_sqrt_rsq(d2n, nrm, rsn);
+      const double t2 = -spx * (rsn * rsn);
       const bool full = !dependent && (!have_t1 || !(t1 < t2));
       if (qo.wave_any(!done && (!full || pcpick)) || WBC_GI_FORCE_BAIL(qc)) { stop = true; return; }   // not a friction add-with-full-step everywhere: generic loop, state untouched
       if (!done) {
@@ -291,9 +293,8 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         sh_ = fmad(t2, sd, sh_);
         // one Householder reflection on d[qc:] (H d2 = alpha e_qc), applied to the own row of J and to the image
         const double dq = d[qc];
-        const double nrm = fast_sqrt(d2n);
         const double alpha = (dq > 0.0) ? -nrm : nrm;
-        const double ia = fast_rcp(alpha);
+        const double ia = (dq > 0.0) ? -rsn : rsn;
         const double beta = fast_rcp(nrm * (nrm + fabs(dq)));   // 2 / (v'v)
         const double vq = dq - alpha;
         const double w = fmad(-alpha, Jr[qc], zd) * beta, wd = fmad(-alpha, Dh[qc], sd) * beta;   // x . v = x . d[qc:] - alpha x_qc
@@ -443,7 +444,9 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     }
     const bool have_t1 = hd >= 0;
     const bool dependent = !(d2n > 1e-22 * dnp) || q == NV;
-    const double t2 = -sp * fast_rcp(d2n);   // n_p' J2 J2' n_p = |d[q:]|^2
+    double nrm_d, rs_d;                           // |d[q:]| and its reciprocal from one seed (as on the fast path)
+    fast_sqrt_rsq(d2n, nrm_d, rs_d);
+    const double t2 = -sp * (rs_d * rs_d);   // n_p' J2 J2' n_p = |d[q:]|^2
     if (live && dependent && !have_t1) { status = ST_SINGULAR; done = true; }
     const bool go = !done;
     const bool full = go && !dependent && (!have_t1 || !(t1 < t2));
@@ -463,7 +466,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     }
     WBC_GI_T(2);   // step
     // ---- the trip's reflection: x onto slot q (append) or, after q - 1, onto the freed slot (drop)
-    double x[NV], n2 = d2n, c_j = zd, c_d = sd, c_p = sdpc, c_t = sdt, c_w = 0.0, c_wp = 0.0, c_wt = 0.0;
+    double x[NV], nrm = nrm_d, rsn = rs_d, c_j = zd, c_d = sd, c_p = sdpc, c_t = sdt, c_w = 0.0, c_wp = 0.0, c_wt = 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) x[k] = dm[k];
     const bool anyd = qo.wave_any(drop);
@@ -577,7 +580,12 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       }
 #pragma unroll
       for (int k = 0; k < NV; k++) x[k] = drop ? w[k] : x[k];
-      n2 = drop ? wn : n2; c_j = drop ? wj : c_j; c_d = drop ? wdh : c_d; c_w = drop ? ww : 0.0;
+      {
+        double nw, rw;
+        fast_sqrt_rsq(wn, nw, rw);
+        nrm = drop ? nw : nrm; rsn = drop ? rw : rsn;
+      }
+      c_j = drop ? wj : c_j; c_d = drop ? wdh : c_d; c_w = drop ? ww : 0.0;
       if (PC) { c_p = drop ? wp1 : c_p; c_wp = drop ? wp2 : 0.0; }
       if (TB) { c_t = drop ? wt1 : c_t; c_wt = drop ? wt2 : 0.0; }
     }
@@ -589,9 +597,8 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
     for (int k = 0; k < NV; k += 2) { xq += eq[k] * x[k]; if (k + 1 < NV) xq1 += eq[k + 1] * x[k + 1]; }
     xq += xq1;
-    const double nrm = fast_sqrt(n2);
     const double alpha = (xq > 0.0) ? -nrm : nrm;
-    const double ia = fast_rcp(alpha);
+    const double ia = (xq > 0.0) ? -rsn : rsn;
     const double beta = (full || (!GIV && drop)) ? fast_rcp(nrm * (nrm + fabs(xq))) : 0.0;   // 2 / (v'v); null reflection for a robot that rests
     // y . v = y . x - alpha y_q (the dots with x are there already; y_q picked by the one-hot mask)
     double jq = 0.0, dhq = 0.0, dpq = 0.0, dtq = 0.0;

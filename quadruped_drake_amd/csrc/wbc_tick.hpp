@@ -98,9 +98,24 @@ __device__ __forceinline__ double fast_sqrt(double x) {
   g = __builtin_fma(e, hh, g);
   return (x > 0.0) ? g : 0.0;
 }
+// sqrt(x) and 1/sqrt(x) of a positive x from ONE seed: the refinement of the root carries h ~ 1/(2 sqrt(x)) along anyway
+__device__ __forceinline__ void fast_sqrt_rsq(double x, double& root, double& rs) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, hh = 0.5 * y;
+  double e = __builtin_fma(-hh, g, 0.5);
+  g = __builtin_fma(g, e, g);
+  hh = __builtin_fma(hh, e, hh);
+  e = __builtin_fma(-g, g, x);
+  g = __builtin_fma(e, hh, g);
+  e = __builtin_fma(-hh, g, 0.5);          // one more step for h: its error was still 2^-50
+  hh = __builtin_fma(hh, e, hh);
+  root = (x > 0.0) ? g : 0.0;
+  rs = hh + hh;
+}
 #else
 WBC_HD double fast_rcp(double x) { return 1.0 / x; }
 WBC_HD double fast_sqrt(double x) { return sqrt(x); }
+WBC_HD void fast_sqrt_rsq(double x, double& root, double& rs) { root = sqrt(x); rs = 1.0 / root; }
 #endif
 
 // one range reduction for both (the f64 sin/cos are long software routines on the GPU)
