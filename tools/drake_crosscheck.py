@@ -85,8 +85,11 @@ def build_plant(pd, ref_root, model, dt, fake):
         parser.AddModelFromFile(urdf, "quad")          # the call simulate.py:40 makes (Drake of 2021-22)
     else:
         parser.AddModels(urdf)                         # its successor in current Drake
-    plant.RegisterCollisionGeometry(plant.world_body(), pd.RigidTransform(), pd.HalfSpace(), "ground_collision",
-                                    pd.CoulombFriction(static_friction=1.0, dynamic_friction=1.0))
+    try:       # the ground of simulate.py:43-52; it takes no part in the quantities compared here, and its signature moved between releases
+        plant.RegisterCollisionGeometry(plant.world_body(), pd.RigidTransform(), pd.HalfSpace(), "ground_collision",
+                                        pd.CoulombFriction(static_friction=1.0, dynamic_friction=1.0))
+    except Exception as e:   # noqa: BLE001
+        print("drake_crosscheck: ground half-space not registered (%s): irrelevant for stage A / B" % type(e).__name__, file=sys.stderr)
     plant.Finalize()
     return plant
 
