@@ -188,6 +188,31 @@ def test_host_pointer_small_batch_goes_through_the_mapped_block():
     host.close()
 
 
+@pytest.mark.parametrize("kind", ["mptc", "pc", "id", "clf"])
+def test_a_robot_does_not_depend_on_its_wave_mates(kind):
+    """Four robots share a wavefront; the wavefront-uniform choices (24- or 30-row append, fast or generic active-set
+    trips) are made for all four together.  Replacing one robot of every wavefront by a flight phase (four swing legs: the
+    30-row append) or by a saturated stand (drops: the generic loop) may not change a bit of the other three."""
+    from quadruped_drake_amd import workloads
+    n = 512
+    b = workloads.make_batch(3, n=n)
+    hard = workloads.make_batch(2, n=n)           # 4-contact stands far outside their friction pyramids
+    ref = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
+    keep = np.arange(n) % 4 != 1
+    for variant in ("flight", "stand"):
+        q, v, tg, mk = (b[k].copy() for k in ("q", "v", "targets", "mask"))
+        if variant == "flight":
+            mk[~keep] = 0
+        else:
+            q[:, ~keep] = hard["q"][:, ~keep]; v[:, ~keep] = hard["v"][:, ~keep]
+            tg[:, ~keep] = hard["targets"][:, ~keep]; mk[~keep] = 0xF
+        out = gpu_step(kind, b["model"], q, v, tg, mk, b["mu"], b["mass_scale"])
+        assert (out[2][keep] == 0).all()
+        assert np.array_equal(out[0][:, keep], ref[0][:, keep]), variant
+        assert np.array_equal(out[1][:, keep], ref[1][:, keep]), variant
+        assert not np.array_equal(out[0][:, ~keep], ref[0][:, ~keep])
+
+
 @pytest.mark.parametrize("cfg,kind,tmax", [(3, "mptc", 10.0), (2, "id", 12.0), (3, "clf", 12.0), (3, "pc", 10.0)])
 def test_torque_box(cfg, kind, tmax):
     """tau_max < inf: 24 more inequality rows (north star: torque-limit inequalities); device pointers, N = 512."""

@@ -239,3 +239,35 @@ def test_givens_drop_build_option_on_host(tmp_path):
         tau_o, met_o, st_o = orc.step_batch(kind, orc.model(b["model"]), orc.params(kind), b["q"], b["v"], b["targets"], b["mask"])
         assert (st == 0).all() and (st_o == 0).all() and stats[2] > 50          # plenty of drops went through the rotations
         assert rel_err(tau, tau_o).max() < 1e-5
+
+
+def test_swing_row_compaction_changes_no_bit(tmp_path):
+    """Task-space laws: a wavefront without a robot of three or four swing legs appends 24 rows (each robot's swing blocks
+    moved up into the first two block slots, csrc/wbc_hex.hpp) instead of 30 with zero rows.  Blocks move by multiples of three rows, so every
+    term keeps its accumulator and its place in the order of the sums: against a build without the compaction
+    (-DWBC_NO_SWING_COMPACT) every contact mask gives the same bits."""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libhost_tick_nocompact.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", "-DWBC_NO_SWING_COMPACT",
+                           "-o", so, os.path.join(root, "tools", "host_tick.cpp")])
+    L = C.CDLL(so)
+    dp = C.POINTER(C.c_double)
+    n = 64
+    b = workloads.make_batch(3, n=n)
+    t = orc.load_model_json(b["model"])
+    mk = (np.arange(n) % 16).astype(np.uint8)          # every contact mask, swing counts 0..4
+    q, v, tg = (np.ascontiguousarray(b[x]) for x in ("q", "v", "targets"))
+    flat = np.ascontiguousarray(t["flat"], dtype=np.float64)
+    for kind, k in (("mptc", 1), ("pc", 2)):
+        tau = np.zeros((12, n)); met = np.zeros((4, n)); st = np.zeros(n, np.int32); it = np.zeros(n, np.int32)
+        rc = L.host_hex_batch(k, flat.ctypes.data_as(dp), None, None, None, n, n, q.ctypes.data_as(dp), v.ctypes.data_as(dp),
+                              tg.ctypes.data_as(dp), mk.ctypes.data_as(C.POINTER(C.c_ubyte)), None, None,
+                              tau.ctypes.data_as(dp), met.ctypes.data_as(dp), st.ctypes.data_as(C.POINTER(C.c_int)),
+                              it.ctypes.data_as(C.POINTER(C.c_int)))
+        assert rc == 0
+        tau_c, met_c, st_c, it_c = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], mk, hexv=True)
+        assert (st == 0).all() and (st_c == 0).all() and np.array_equal(it, it_c)
+        assert np.array_equal(tau_c, tau) and np.array_equal(met_c, met)
