@@ -688,9 +688,9 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 // 6x6 solve without row exchanges for NR right-hand sides held as extra columns.  G_b = M_bb - sum X Jfb is
 // the base's 6x6 composite inertia (symmetric positive definite, dominant) minus the light legs' coupling,
 // so elimination in natural order is stable; a collapsed pivot is reported through the returned
-// min|pivot| / max|pivot| exactly like the pivoted solve6 (the caller turns it into status 2).
+// "min|pivot| > 1e-12 max|pivot|" (false also for NaN; the caller turns it into status 2) -- a product, not a quotient.
 // Row exchanges on register arrays cost ~400 v_cndmask per tick on this kernel.
-template <int NR> WBC_HD double solve6np(double (*Ab)[6 + NR]) {
+template <int NR> WBC_HD bool solve6np(double (*Ab)[6 + NR]) {
   double pmin = 0.0, pmax = 0.0;
 #pragma unroll
   for (int c = 0; c < 6; c++) {
@@ -717,7 +717,7 @@ template <int NR> WBC_HD double solve6np(double (*Ab)[6 + NR]) {
       Ab[c][6 + n] = sacc;
     }
   }
-  return pmin / pmax;
+  return pmin > 1e-12 * pmax;
 }
 
 // Robot-level cold storage ("park"): replicated values that are produced early and consumed late
@@ -1056,8 +1056,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
       const double xc = pick3(sb, X[3 * i], X[3 * i + 1], X[3 * i + 2]);
       Ab[i][6] = colv ? (ct ? wc[i] : -xc) : -kv[i];
     }
-    const double rc = solve6np<1>(Ab);
-    if (!(rc > 1e-12)) status = ST_SINGULAR;
+    if (!solve6np<1>(Ab)) status = ST_SINGULAR;
     for (int i = 0; i < 6; i++) {
       bcol[i] = Ab[i][6];
       ab0[i] = qo.leg_bcast(bcol[i], 3);
@@ -1089,7 +1088,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
     else { dval = 0.0; drhs = 0.0; }
 #pragma unroll
     for (int k = 0; k < NZ; k++) {
-      const double rk = qo.bcast16(drhs, hex_lane(k));
+      const double rk = (KIND == KIND_MPTC || KIND == KIND_PC) ? 0.0 : qo.bcast16(drhs, hex_lane(k));   // task-space laws: no right-hand side on the diagonal rows
       Rcol[k] = colv ? ((hex_lane(k) == h) ? dval : 0.0) : (cold ? 0.0 : rk);
     }
     if (KIND == KIND_CLF) Rcol[NV - 1] = cold ? sqrt(2.0 * 1000.0) : 0.0;   // w_delta delta^2 = 1/2 (sqrt(2 w) delta)^2  (:73,:206)
@@ -1389,7 +1388,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
 #pragma unroll
       for (int k = 0; k < NV; k++) x = (hex_lane(k) == h) ? Rcol[k] : x;
       return x; }();
-    const double inv_own = 1.0 / rown;
+    const double inv_own = fast_rcp(rown);
     double invd[NV];
 #pragma unroll
     for (int c = 0; c < NV; c++) invd[c] = qo.bcast16(inv_own, hex_lane(c));
@@ -1432,18 +1431,20 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   // ---------------- friction rows (+ the optional torque box)
   int iters = 0;
   {
-    const double s = sqrt(1.0 + mu * mu);
+    double s, rs;   // sqrt(1 + mu^2) and its reciprocal from one hardware seed
+    fast_sqrt_rsq(1.0 + mu * mu, s, rs);
+    (void)s;
     int st;
     if (KIND == KIND_PC) {
-      st = hex_gi<Q, true, NV, TB, false, WBC_GIVENS_DROPS != 0>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt);
+      st = hex_gi<Q, true, NV, TB, false, WBC_GIVENS_DROPS != 0>(qo, h, ct, Jr, z, mu * rs, rs, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt);
     } else if (KIND == KIND_CLF) {
       // the CLF row  g . [z; delta] - ub <= 0  is the dense row of the active set (index 16), like PC's Vdot row
-      st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt);
+      st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu * rs, rs, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt);
     } else {
 #ifndef WBC_GAIN_ID
 #define WBC_GAIN_ID 0
 #endif
-      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC || (WBC_GAIN_ID && KIND == KIND_ID)) && !TB, (WBC_GIVENS_DROPS != 0) && KIND == KIND_MPTC>(qo, h, ct, Jr, z, mu / s, 1.0 / s, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt);
+      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC || (WBC_GAIN_ID && KIND == KIND_ID)) && !TB, (WBC_GIVENS_DROPS != 0) && KIND == KIND_MPTC>(qo, h, ct, Jr, z, mu * rs, rs, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt);
     }
     if (st != ST_OK) status = st;
     if (status == ST_OK && illc) status = ST_ILLCOND;
