@@ -759,7 +759,7 @@ WBC_HD double pick3(int sb, double a, double b, double c) { return (sb == 0) ? a
 // The tick.  Every lane of the row calls this with its own Q (lane id h = 4*leg + sub).
 // out_tau(row, x): lane (leg, j<3) writes the torque of joint 3*leg+j;  out_met: see the kernel.
 template <class Q, int KIND, bool TB, class Park, class In, class OutTau, class OutMet>
-WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned mask, double mu, double mass_scale,
+WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned mask, double mu, double mass_scale,
                     Park& pk, OutTau out_tau, OutMet out_met, int* iters_out) {
   const int h = qo.lane();
   const int l = h >> 2, sb = h & 3;
@@ -1065,8 +1065,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsC& P, Q& qo, In in, unsigned ma
   WBC_STAMP(12);
   WBC_HCUT_AT(3, bcol[0] + bcol[5] + ab0[2] + Cb_leg[2] + Cl[1] + xi[0] + t0_own + Yrow[2] + Drow[1] + Y[4] + Ji[4] + Mll6[2] + jdxi[0] + xt_s[0] + xdt_s[1] + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1] + kv[0])
   // ---------------- level-1 rows
-  const double eps = sqrt(P.eps2);
-  const double sw_b = sqrt(P.w_body), sw_f = sqrt(P.w_foot);
+  const double eps = P.sq_eps, sw_b = P.sq_w_body, sw_f = P.sq_w_foot;   // formed once on the host (ParamsX)
   double Rcol[NV];
   double met_err = 0.0;
   for (int i = 0; i < 6; i++) met_err += xt_b[i] * xt_b[i];

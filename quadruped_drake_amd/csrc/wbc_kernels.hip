@@ -294,7 +294,7 @@ __device__ __forceinline__ int hex_effective_block(int b, int nblocks) {
 #endif
 template <int KIND, bool TB = false>
 __global__ void __launch_bounds__(HEX_BLOCK) __attribute__((amdgpu_waves_per_eu(WBC_HEX_WAVES_PER_EU)))
-wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld,
+wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* __restrict__ pp, int n, int ld,
                const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
                const uint8_t* __restrict__ mask, const double* __restrict__ mu,
                const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
@@ -349,7 +349,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
   __syncthreads();
   WBC_STAMP(3);
   const wbc::ModelC& m = *reinterpret_cast<const wbc::ModelC*>(mbuf);
-  const wbc::ParamsC& P = *pp;
+  const wbc::ParamsX& P = *pp;
   HexDev qo;
   auto in = [&](int r) -> double { return inbuf[r * HROBOTS + slot]; };
   double tsum = 0.0, tmax = 0.0, errv = 0.0;
@@ -401,7 +401,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restric
 // bit for bit (tests/test_rollout.py).
 template <int KIND, bool TB>
 __global__ void __launch_bounds__(HEX_BLOCK)
-wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* __restrict__ pp, int n, int ld, int steps,
+wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* __restrict__ pp, int n, int ld, int steps,
                        double dt, wbc::TrajDev T, double* __restrict__ q, double* __restrict__ v, double* __restrict__ time,
                        double* __restrict__ tg, uint8_t* __restrict__ mask, const double* __restrict__ mu,
                        const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
@@ -452,9 +452,9 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsC* _
     // SGPR pairs across the whole loop body)
     qo.h = h + zoff;
     const wbc::ModelC& m = *reinterpret_cast<const wbc::ModelC*>(mbuf + zoff);
-    const wbc::ParamsC* ppi = pp;
+    const wbc::ParamsX* ppi = pp;
     asm volatile("" : "+s"(ppi));
-    const wbc::ParamsC& P = *ppi;
+    const wbc::ParamsX& P = *ppi;
     const double tnow = robuf[slot * 4 + 0], mui = robuf[slot * 4 + 2], msi = robuf[slot * 4 + 3];
     const int hint = (int)robuf[slot * 4 + 1];
     // ---- targets and contact mask of this tick (planners/towr.py:92-148)
@@ -606,7 +606,7 @@ struct wbc_handle_s {
   hipStream_t stream;
   bool own_stream;
   wbc::ModelC* d_model;
-  wbc::ParamsC* d_params;
+  wbc::ParamsX* d_params;
   StatsDev* d_stats;
   StatsDev* h_stats;  // pinned, device-mapped: the reduce kernel writes the totals straight into host memory
   hipEvent_t ev0, ev1;
@@ -693,7 +693,7 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
     HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = true;
     HIP_TRY(hipMalloc(&h->d_model, (size_t)MODEL_REPLICAS * MODEL_PAD_WORDS * 8));
-    HIP_TRY(hipMalloc(&h->d_params, sizeof P));
+    HIP_TRY(hipMalloc(&h->d_params, sizeof(wbc::ParamsX)));
     HIP_TRY(hipMalloc(&h->d_stats, sizeof(StatsDev) * (STAT_SLOTS + 1)));
     {
       // MODEL_REPLICAS padded copies: concurrent workgroups read different lines / channels
@@ -703,7 +703,11 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
       delete[] rep;
       if (e != hipSuccess) return fail("hipMemcpy(model replicas)", e);
     }
-    HIP_TRY(hipMemcpy(h->d_params, &P, sizeof P, hipMemcpyHostToDevice));
+    {
+      wbc::ParamsX PX;
+      wbc::params_derive(P, &PX);
+      HIP_TRY(hipMemcpy(h->d_params, &PX, sizeof PX, hipMemcpyHostToDevice));
+    }
     HIP_TRY(hipMemset(h->d_stats, 0, sizeof(StatsDev) * (STAT_SLOTS + 1)));
     HIP_TRY(hipHostMalloc(&h->h_stats, sizeof(StatsDev), hipHostMallocMapped));
     HIP_TRY(hipEventCreate(&h->ev0));

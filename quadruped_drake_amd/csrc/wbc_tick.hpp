@@ -171,6 +171,15 @@ struct ParamsC {
   double Kp_body_p, Kd_body_p, Kp_body_rpy, Kd_body_rpy, Kp_foot, Kd_foot;
   double w_body, w_foot, mu, Kd_contact, tau_max, eps2;
 };
+// The kernel's view: the public POD plus the three square roots every robot of every tick would otherwise form from it
+// (correctly rounded on the host as on the device: the same bits, ~60 instructions per tick less).
+struct ParamsX : ParamsC {
+  double sq_eps, sq_w_body, sq_w_foot;
+};
+inline void params_derive(const ParamsC& p, ParamsX* x) {
+  static_cast<ParamsC&>(*x) = p;
+  x->sq_eps = sqrt(p.eps2); x->sq_w_body = sqrt(p.w_body); x->sq_w_foot = sqrt(p.w_foot);
+}
 
 // ---------------------------------------------------------------- tiny vector helpers
 template <class T> WBC_HD void cross(const T* a, const T* b, T* c) {

@@ -275,11 +275,13 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
                               const double* tg, const unsigned char* mask, const double* mu,
                               const double* mass_scale, double* tau, double* met, int* status, int* iters) {
   static wbc::ModelC m;
-  static wbc::ParamsC P;
+  static wbc::ParamsC P0;
+  static wbc::ParamsX P;
   if (wbc::model_from_flat(flat215, &m)) return -1;
   wbc::model_set_perms(&m, q_perm, act_perm);
-  wbc::params_default(kind, &P);
-  if (params12) memcpy(&P, params12, sizeof(double) * 12);
+  wbc::params_default(kind, &P0);
+  if (params12) memcpy(&P0, params12, sizeof(double) * 12);
+  wbc::params_derive(P0, &P);
   static HexCtx ctx;
   g_hex = &ctx;
   const size_t STK = 1 << 20;
