@@ -230,6 +230,13 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #endif
   constexpr int QF = (!TB && NV == NZ) ? (GAIN ? 8 : WBC_QF_ID) : 0;   // ID stands add up to 8-12 rows before the first drop; PC: see pcv below
   bool generic = true;   // wave-uniform: the generic loop still has work to do
+  // What an abandoned fast trip has already worked out -- pick, the picked row's image, the step's dots, the blocking ratio, the norm --
+  // is the front half of a generic trip, evaluated by the same expressions: the first generic trip takes it over instead of
+  // repeating the argmin, the crossbar round trip and the dots (~1300 cycles on every wavefront that leaves the fast path; on a trot
+  // batch those few wavefronts are the launch's tail: MPTC trot N = 4096 -2 %).  Friction-only laws (ID, MPTC).
+  bool handed = false;   // wave-uniform
+  int ho_p = -1, ho_hd = -1;
+  double ho_d[NV], ho_sp = 0.0, ho_dn = 1.0, ho_d2n = 0.0, ho_zd = 0.0, ho_sd = 0.0, ho_r = 0.0, ho_t1 = 0.0;
   if constexpr (QF > 0) {
     bool stop = false;   // wave-uniform
     static_for<QF>([&](auto QQ) {
@@ -284,7 +291,19 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       fast_sqrt_rsq(d2n, nrm, rsn);
       const double t2 = -spx * (rsn * rsn);
       const bool full = !dependent && (!have_t1 || !(t1 < t2));
-      if (qo.wave_any(!done && (!full || pcpick)) || WBC_GI_FORCE_BAIL(qc)) { stop = true; return; }   // not a friction add-with-full-step everywhere: generic loop, state untouched
+      if (qo.wave_any(!done && (!full || pcpick)) || WBC_GI_FORCE_BAIL(qc)) {   // not a friction add-with-full-step everywhere: generic loop, state untouched
+        stop = true;
+#ifndef WBC_NO_HANDOVER
+        if constexpr (!PC) {   // (measured on the PC law, whose dense row sends ~20 % of the wavefronts here: +2 % -- not taken over there)
+          handed = true;
+          ho_p = pf; ho_sp = spx; ho_dn = dnx; ho_d2n = d2n; ho_zd = zd; ho_sd = sd; ho_r = r_h;
+          ho_t1 = t1; ho_hd = have_t1 ? hex_key_index(t1) : -1;
+#pragma unroll
+          for (int k = 0; k < NZ; k++) ho_d[k] = d[k];
+        }
+#endif
+        return;
+      }
       if (!done) {
         iters++;
         WBC_GI_STAT(if (h == 0) g_gi_fast_trips++);
@@ -335,112 +354,125 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   WBC_GI_TIMERS;
   for (int trip = 0; generic && trip < maxit; trip++) {
     WBC_GI_T0();
-    if (!done && need_pick) {
-      // most violated inactive row: argmin of the tracked values (friction slot: index h, torque slot: 16 + h)
-      {
-        double key = HEX_NONE;
-        if (GAIN) {
-          // greatest dual gain s^2 / |D_h[q:]|^2 instead of the most violated row: fewer iterations for the worst
-          // robots of a trot batch (max 7 -> 6, rows needing >= 5: 88 -> 32 of 4096), more for the 4-contact ID stand
-          double dd2 = 0.0;
-#pragma unroll
-          for (int k = 0; k < NV; k++) dd2 = fmad(mk[k] * Dh[k], Dh[k], dd2);
-          // a violated row whose image has no free part (linearly dependent on the active ones) must still be
-          // picked -- the dependent-step logic below resolves or reports it -- so it gets the largest finite gain
-          if (ct && !act_h && sh_ < -tol)
-            key = hex_pack_key((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
-        } else {
-          if (ct && !act_h) key = hex_pack_key(sh_, h);
-        }
-        if (TB) {
-          const double st_ = bt - fabs(yt);
-          if (elig_t && !act_t && st_ < key) key = hex_pack_key(st_, 16 + h);
-        }
-        key = qo.min16(key);
-        const int ix = hex_key_index(key);
-        sp = key;
-        p = (key < 1e299) ? ((ix < 16) ? ix : 16 + ix) : -1;   // torque slot ids are 32 + lane
-        if (p < 0) sp = INF;
-      }
-      picked = true;
-    }
-    // ONE round trip through the lane crossbar per trip: the image of the (newly or previously) picked row and, for a new
-    // pick, its exact value (the key carries index bits, or is the gain), its norm and -- torque rows -- its violated side
-    WBC_GI_T(0);   // pick
-    const int pl = (p >= 0 && p != 16) ? (p & 15) : h;
-    const bool trow = TB && p >= 32;
     double d[NV], dm[NV], d2n = 0.0;
+    double zd = 0.0, sd = 0.0, sdpc = 0.0, sdt = 0.0;
+    double r_h = 0.0, r_pc = 0.0, r_t = 0.0;
+    double t1 = INF;
+    int hd = -1;
+    const bool takeover = handed && trip == 0;   // wave-uniform
+    bool all_done = false;
+    if (!takeover) {
+      if (!done && need_pick) {
+        // most violated inactive row: argmin of the tracked values (friction slot: index h, torque slot: 16 + h)
+        {
+          double key = HEX_NONE;
+          if (GAIN) {
+            // greatest dual gain s^2 / |D_h[q:]|^2 instead of the most violated row: fewer iterations for the worst
+            // robots of a trot batch (max 7 -> 6, rows needing >= 5: 88 -> 32 of 4096), more for the 4-contact ID stand
+            double dd2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < NV; k++) d[k] = qo.bcast16d(trow ? Dt[k] : Dh[k], pl);
-    const double sp_x = qo.bcast16d(sh_, pl), dn_x = qo.bcast16d(trow ? dnt : dnh, pl);
-    double sg_x = 1.0;
-    if (TB) sg_x = qo.bcast16d((yt > 0.0) ? -1.0 : 1.0, pl);
-    if (picked) {
-      picked = false;
-      if (p >= 0 && p < 16) sp = sp_x;
-      if (pc && !act_pc && spc < sp) { sp = spc; p = 16; }
-      if (!(sp < -tol)) p = -1;
-      if (p < 0) {
-        done = true;
-      } else {
-        up = 0.0;
-        dnp = dn_x;
-        if (PC) dnp = (p == 16) ? dnpc : dnp;
-        if (TB) sgp = (p >= 32) ? sg_x : 1.0;   // violated side of a torque row
-        need_pick = false;
+            for (int k = 0; k < NV; k++) dd2 = fmad(mk[k] * Dh[k], Dh[k], dd2);
+            // a violated row whose image has no free part (linearly dependent on the active ones) must still be
+            // picked -- the dependent-step logic below resolves or reports it -- so it gets the largest finite gain
+            if (ct && !act_h && sh_ < -tol)
+              key = hex_pack_key((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
+          } else {
+            if (ct && !act_h) key = hex_pack_key(sh_, h);
+          }
+          if (TB) {
+            const double st_ = bt - fabs(yt);
+            if (elig_t && !act_t && st_ < key) key = hex_pack_key(st_, 16 + h);
+          }
+          key = qo.min16(key);
+          const int ix = hex_key_index(key);
+          sp = key;
+          p = (key < 1e299) ? ((ix < 16) ? ix : 16 + ix) : -1;   // torque slot ids are 32 + lane
+          if (p < 0) sp = INF;
+        }
+        picked = true;
       }
+      // ONE round trip through the lane crossbar per trip: the image of the (newly or previously) picked row and, for a new
+      // pick, its exact value (the key carries index bits, or is the gain), its norm and -- torque rows -- its violated side
+      WBC_GI_T(0);   // pick
+      const int pl = (p >= 0 && p != 16) ? (p & 15) : h;
+      const bool trow = TB && p >= 32;
+#pragma unroll
+      for (int k = 0; k < NV; k++) d[k] = qo.bcast16d(trow ? Dt[k] : Dh[k], pl);
+      const double sp_x = qo.bcast16d(sh_, pl), dn_x = qo.bcast16d(trow ? dnt : dnh, pl);
+      double sg_x = 1.0;
+      if (TB) sg_x = qo.bcast16d((yt > 0.0) ? -1.0 : 1.0, pl);
+      if (picked) {
+        picked = false;
+        if (p >= 0 && p < 16) sp = sp_x;
+        if (pc && !act_pc && spc < sp) { sp = spc; p = 16; }
+        if (!(sp < -tol)) p = -1;
+        if (p < 0) {
+          done = true;
+        } else {
+          up = 0.0;
+          dnp = dn_x;
+          if (PC) dnp = (p == 16) ? dnpc : dnp;
+          if (TB) sgp = (p >= 32) ? sg_x : 1.0;   // violated side of a torque row
+          need_pick = false;
+        }
+      }
+      WBC_GI_T(1);   // fetch
+      all_done = qo.wave_all(done);
     }
-    WBC_GI_T(1);   // fetch
-    if (qo.wave_all(done)) break;
+    if (all_done) break;
     // from here on the trip is straight-line code: a finished robot runs along with a zero step and a null reflection
     const bool live = !done;
     if (live) iters++;
     WBC_GI_STAT(if (h == 0 && live) g_gi_generic_trips++);
+    if (!takeover) {
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-      if (TB) d[k] = sgp * d[k];
-      if (PC) d[k] = (p == 16) ? Dpc[k] : d[k];
-      dm[k] = d[k] * mk[k];
-      d2n = fmad(dm[k], dm[k], d2n);
-    }
-    double zd = 0.0, sd = 0.0, sdpc = 0.0, sdt = 0.0;
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-      zd = fmad(Jr[k], dm[k], zd);
-      sd = fmad(Dh[k], dm[k], sd);
-      if (PC) sdpc = fmad(Dpc[k], dm[k], sdpc);
-      if (TB) sdt = fmad(Dt[k], dm[k], sdt);
-    }
-    // dual step direction r = R^-1 d[0:q]: every active row's lane holds its row of W = R^-1
-    // (slots k >= q of every W row are zero by construction, so d needs no masking here)
-    double r_h = 0.0, r_pc = 0.0, r_t = 0.0;
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-      r_h = fmad(Wr[k], d[k], r_h);
-      if (PC) r_pc = fmad(Wpc[k], d[k], r_pc);
-      if (TB) r_t = fmad(Wt[k], d[k], r_t);
-    }
-    r_h = act_h ? r_h : 0.0;
-    if (PC) r_pc = act_pc ? r_pc : 0.0;
-    if (TB) r_t = act_t ? r_t : 0.0;
-    // blocking multiplier: min over active rows with r > 0 of u / r
-    double t1 = INF;
-    int hd = -1;
-    {
-      double key = (act_h && r_h > 0.0) ? hex_pack_key(u_h * fast_rcp(r_h), h) : HEX_NONE;
-      if (TB) {
-        const double c = (act_t && r_t > 0.0) ? u_t * fast_rcp(r_t) : HEX_NONE;
-        if (c < key) key = hex_pack_key(c, 16 + h);
+      for (int k = 0; k < NV; k++) {
+        if (TB) d[k] = sgp * d[k];
+        if (PC) d[k] = (p == 16) ? Dpc[k] : d[k];
+        dm[k] = d[k] * mk[k];
+        d2n = fmad(dm[k], dm[k], d2n);
       }
-      key = qo.min16(key);
-      const int ix = hex_key_index(key);
-      const bool any = key < 1e299;
-      t1 = any ? key : INF;
-      hd = any ? ((ix < 16) ? ix : 16 + ix) : -1;
-      if (PC) {
-        const double c = (act_pc && r_pc > 0.0) ? u_pc * fast_rcp(r_pc) : INF;
-        if (c < t1) { t1 = c; hd = 16; }
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        zd = fmad(Jr[k], dm[k], zd);
+        sd = fmad(Dh[k], dm[k], sd);
+        if (PC) sdpc = fmad(Dpc[k], dm[k], sdpc);
+        if (TB) sdt = fmad(Dt[k], dm[k], sdt);
       }
+      // dual step direction r = R^-1 d[0:q]: every active row's lane holds its row of W = R^-1
+      // (slots k >= q of every W row are zero by construction, so d needs no masking here)
+#pragma unroll
+      for (int k = 0; k < NV; k++) {
+        r_h = fmad(Wr[k], d[k], r_h);
+        if (PC) r_pc = fmad(Wpc[k], d[k], r_pc);
+        if (TB) r_t = fmad(Wt[k], d[k], r_t);
+      }
+      r_h = act_h ? r_h : 0.0;
+      if (PC) r_pc = act_pc ? r_pc : 0.0;
+      if (TB) r_t = act_t ? r_t : 0.0;
+      // blocking multiplier: min over active rows with r > 0 of u / r
+      {
+        double key = (act_h && r_h > 0.0) ? hex_pack_key(u_h * fast_rcp(r_h), h) : HEX_NONE;
+        if (TB) {
+          const double c = (act_t && r_t > 0.0) ? u_t * fast_rcp(r_t) : HEX_NONE;
+          if (c < key) key = hex_pack_key(c, 16 + h);
+        }
+        key = qo.min16(key);
+        const int ix = hex_key_index(key);
+        const bool any = key < 1e299;
+        t1 = any ? key : INF;
+        hd = any ? ((ix < 16) ? ix : 16 + ix) : -1;
+        if (PC) {
+          const double c = (act_pc && r_pc > 0.0) ? u_pc * fast_rcp(r_pc) : INF;
+          if (c < t1) { t1 = c; hd = 16; }
+        }
+      }
+    } else {
+      // the abandoned fast trip's front half (a finished robot's values are never used: zero step, null reflection)
+      p = ho_p; sp = ho_sp; dnp = ho_dn; up = 0.0; need_pick = false;   // norm, 1/norm and the full step length follow from d2n and sp below, as on the fast path
+#pragma unroll
+      for (int k = 0; k < NV; k++) { d[k] = ho_d[k]; dm[k] = d[k] * mk[k]; }
+      d2n = ho_d2n; zd = ho_zd; sd = ho_sd; r_h = ho_r; t1 = (ho_hd >= 0) ? ho_t1 : INF; hd = ho_hd;
     }
     const bool have_t1 = hd >= 0;
     const bool dependent = !(d2n > 1e-22 * dnp) || q == NV;
