@@ -272,7 +272,8 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       // the dense row wins the pick when it is the most violated one (generic loop: spc < sp)
       const bool pcpick = pcv && !(pf >= 0 && !(spc < spx));
       if (!(pf >= 0 && spx < -tol) && !pcpick) done = true;        // nothing (left) to repair on this robot
-      if (qo.wave_all(done)) { stop = true; generic = false; return; }
+      // (with the gain pick only violated rows are candidates: a robot with a candidate stays live, the test above was the exit)
+      if (!GAIN && qo.wave_all(done)) { stop = true; generic = false; return; }
       double d2n = 0.0, zd = 0.0, sd = 0.0, r_h = 0.0;
       static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; d2n = fmad(d[k], d[k], d2n); });
       static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; zd = fmad(Jr[k], d[k], zd); sd = fmad(Dh[k], d[k], sd); });
