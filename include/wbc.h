@@ -177,6 +177,9 @@ int wbc_variant_for(wbc_handle h, int n);
 /* Kernel resource report for the variant of the most recent launch (or of max_batch before any):
  * registers, scratch bytes/lane, LDS bytes. */
 int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads);
+/* The same for the persistent closed-loop kernel wbc_rollout launches for this handle (its own register allocation: the tick
+ * inlined into the step loop). */
+int wbc_rollout_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads);
 
 /* ------------------------------------------------------------------------------------------
  * Callers of the path: trunk-trajectory wire format and target lookup.

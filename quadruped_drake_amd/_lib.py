@@ -16,7 +16,7 @@ DEVICE_PTRS, HOST_PTRS = 0, 1
 # every symbol include/wbc.h declares
 SYMBOLS = ["wbc_last_error", "wbc_version", "wbc_params_default", "wbc_create", "wbc_destroy", "wbc_set_stream",
            "wbc_step", "wbc_sync", "wbc_time_steps", "wbc_time_steps_result", "wbc_time_steps_each", "wbc_stats_get", "wbc_stats_reset", "wbc_set_variant", "wbc_set_vdot_output", "wbc_integrate", "wbc_rollout",
-           "wbc_kernel_info", "wbc_variant_for", "wbc_trunk_state_decode", "wbc_trunk_state_to_targets", "wbc_traj_create",
+           "wbc_kernel_info", "wbc_rollout_kernel_info", "wbc_variant_for", "wbc_trunk_state_decode", "wbc_trunk_state_to_targets", "wbc_traj_create",
            "wbc_traj_destroy", "wbc_traj_lookup", "wbc_robot_state_decode", "wbc_robot_state_encode",
            "wbc_robot_states_unpack", "wbc_robot_controls_pack", "wbc_pd_step"]
 

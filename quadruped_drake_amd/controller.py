@@ -284,9 +284,11 @@ class BatchedController:
             _lib.check(v)
         return {3: "hex"}[v]
 
-    def kernel_info(self):
+    def kernel_info(self, rollout=False):
+        """Registers, scratch bytes per lane and LDS bytes of the tick kernel (rollout=True: of the persistent closed-loop kernel)."""
         a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
-        _lib.check(self._L.wbc_kernel_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        fn = self._L.wbc_rollout_kernel_info if rollout else self._L.wbc_kernel_info
+        _lib.check(fn(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
         return dict(num_regs=a.value, scratch_bytes_per_lane=b.value, lds_bytes=c.value, block_threads=d.value)
 
     # -- single-robot convenience with the reference's signature --------------------------

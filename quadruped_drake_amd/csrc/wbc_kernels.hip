@@ -1051,4 +1051,29 @@ int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_by
   return 0;
 }
 
+int wbc_rollout_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads) {
+  if (!h) return misuse("wbc_rollout_kernel_info: null handle");
+  hipFuncAttributes a;
+  const void* fn;
+#ifdef WBC_DEV_ONLY
+  (void)fn; (void)a;
+  return misuse("wbc_rollout_kernel_info: not part of a WBC_DEV_ONLY diagnostic build");
+#else
+  if (h->torque_box)
+    fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_rollout_kernel<wbc::KIND_ID, true>
+       : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_rollout_kernel<wbc::KIND_MPTC, true>
+       : h->kind == WBC_KIND_PC ? (const void*)wbc_hex_rollout_kernel<wbc::KIND_PC, true> : (const void*)wbc_hex_rollout_kernel<wbc::KIND_CLF, true>;
+  else
+    fn = h->kind == WBC_KIND_ID ? (const void*)wbc_hex_rollout_kernel<wbc::KIND_ID, false>
+       : h->kind == WBC_KIND_MPTC ? (const void*)wbc_hex_rollout_kernel<wbc::KIND_MPTC, false>
+       : h->kind == WBC_KIND_PC ? (const void*)wbc_hex_rollout_kernel<wbc::KIND_PC, false> : (const void*)wbc_hex_rollout_kernel<wbc::KIND_CLF, false>;
+#endif
+  HIP_TRY(hipFuncGetAttributes(&a, fn));
+  if (num_vgpr) *num_vgpr = a.numRegs;
+  if (scratch_bytes) *scratch_bytes = (int)a.localSizeBytes;
+  if (lds_bytes) *lds_bytes = (int)a.sharedSizeBytes;
+  if (block_threads) *block_threads = HEX_BLOCK;
+  return 0;
+}
+
 }  // extern "C"

@@ -110,3 +110,12 @@ def test_dpp_hazard_lint_flags_a_violation_and_passes_clean_code(tmp_path):
     assert subprocess.run([sys.executable, tool, str(dirty)], capture_output=True).returncode == 1
     r = subprocess.run([sys.executable, tool, str(clean)], capture_output=True, text=True)
     assert r.returncode == 0 and "2 fused" in r.stdout
+    # the same tool refuses a kernel that spills to scratch (code-object metadata)
+    meta = "amdhsa.kernels:\n  - .agpr_count:     0\n    .name:           _Zk\n    .private_segment_fixed_size: %d\n    .vgpr_count: 12\n    .wavefront_size: 64\n"
+    spill = tmp_path / "spill.s"
+    spill.write_text(clean.read_text() + meta % 96)
+    ok = tmp_path / "ok.s"
+    ok.write_text(clean.read_text() + meta % 0)
+    r = subprocess.run([sys.executable, tool, str(spill)], capture_output=True, text=True)
+    assert r.returncode == 1 and "_Zk: 96 B/lane" in r.stdout
+    assert subprocess.run([sys.executable, tool, str(ok)], capture_output=True).returncode == 0

@@ -284,3 +284,18 @@ def test_persistent_rollout_long_and_ragged():
     assert np.array_equal(tg_a.cpu().numpy()[:, 0], tg[-1])          # past the end: the last sample
     assert ca.stats()["ticks"] == steps * n
     ca.close(); cb.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tau_max", [None, 12.0])
+def test_no_product_kernel_spills(tau_max):
+    """The runtime's view of what build() checks in the code object: the tick kernel AND the persistent rollout kernel of every
+    law run without a private segment (the rollout kernels carried 100 - 300 B/lane of scratch until the resource report
+    looked at them: wbc_rollout_kernel_info)."""
+    from quadruped_drake_amd import IDController, MPTCController, PCController, CLFController
+    for cls in (IDController, MPTCController, PCController, CLFController):
+        c = cls(max_batch=64, device=0, params=None if tau_max is None else {"tau_max": tau_max})
+        tick, ro = c.kernel_info(), c.kernel_info(rollout=True)
+        c.close()
+        assert tick["scratch_bytes_per_lane"] == 0 and ro["scratch_bytes_per_lane"] == 0, (cls.__name__, tick, ro)
+        assert 0 < tick["num_regs"] <= 512 and 0 < ro["num_regs"] <= 512

@@ -69,7 +69,7 @@ def run(name, outdir):
         for _ in range(4):
             c.rollout(traj, steps, dt, q, v, t)
         c.sync()
-        info.update(n=n, law=cls.__name__, steps_per_launch=steps, kernel_info=c.kernel_info(), match="wbc_hex_rollout_kernel")
+        info.update(n=n, law=cls.__name__, steps_per_launch=steps, kernel_info=c.kernel_info(rollout=True), match="wbc_hex_rollout_kernel")
         c.close()
     elif name == "lookup":
         n, K = 4096, 5001

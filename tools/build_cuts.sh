@@ -4,7 +4,7 @@
 cd /root/repo; mkdir -p build_variants
 kind=1; if [ "$1" = "-k" ]; then kind=$2; shift 2; fi
 for k in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-atomic-optimizer-strategy=None -fPIC -shared -DWBC_DEV_ONLY=$kind -DWBC_HCUT=$k -o build_variants/hcut$k.so quadruped_drake_amd/csrc/wbc_kernels.hip quadruped_drake_amd/csrc/wbc_traj.hip 2>/dev/null &
+  /opt/rocm/bin/hipcc $(cat /root/repo/quadruped_drake_amd/csrc/hipcc_flags.txt) -fPIC -shared -DWBC_DEV_ONLY=$kind -DWBC_HCUT=$k -o build_variants/hcut$k.so quadruped_drake_amd/csrc/wbc_kernels.hip quadruped_drake_amd/csrc/wbc_traj.hip 2>/dev/null &
   if (( $(jobs -r | wc -l) >= 6 )); then wait -n; fi
 done
 wait

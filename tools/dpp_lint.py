@@ -74,9 +74,28 @@ def lint(path):
     return bad, n_dpp, n_fused
 
 
+def scratch(path):
+    """Second check on the same file: no kernel of the product may spill to scratch (the code object's metadata:
+    .private_segment_fixed_size per kernel).  The persistent rollout kernels did for two rounds -- machine LICM hoisted the
+    tick's literal constants out of the step loop and the allocator spilled them -- while the resource report only looked at
+    the tick kernels."""
+    txt = open(path).read()
+    out = []
+    for blk in re.findall(r"- \.agpr_count:.*?\.wavefront_size", txt, re.S):
+        nm = re.search(r"\.name:\s+(\S+)", blk)
+        ps = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+        if nm and ps:
+            out.append((nm.group(1), int(ps.group(1))))
+    return out
+
+
 if __name__ == "__main__":
     bad, n_dpp, n_fused = lint(sys.argv[1])
     print("dpp_lint: %d DPP instructions (%d fused v_fmac_f64_dpp), %d hazard violations" % (n_dpp, n_fused, len(bad)))
     for ln, line, prev in bad[:20]:
         print("  line %d: %s\n      <- written by: %s" % (ln, line, prev))
-    sys.exit(1 if bad else 0)
+    ks = scratch(sys.argv[1])
+    spilled = [(n, b) for n, b in ks if b > 0]
+    if ks:
+        print("scratch: %d kernels, %d with a private segment%s" % (len(ks), len(spilled), "".join("\n  %s: %d B/lane" % x for x in spilled)))
+    sys.exit(1 if (bad or spilled) else 0)

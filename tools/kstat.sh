@@ -2,7 +2,7 @@
 # kernel resource + instruction-mix report:  tools/kstat.sh [kernel-substring] [extra hipcc flags...]
 k=${1:-wbc_hex_kernelILi1E}; shift
 mkdir -p /tmp/asm; cd /tmp/asm
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-atomic-optimizer-strategy=None "$@" -S --cuda-device-only -o ks.s /root/repo/quadruped_drake_amd/csrc/wbc_kernels.hip 2>/dev/null || exit 1
+/opt/rocm/bin/hipcc $(cat /root/repo/quadruped_drake_amd/csrc/hipcc_flags.txt) "$@" -S --cuda-device-only -o ks.s /root/repo/quadruped_drake_amd/csrc/wbc_kernels.hip 2>/dev/null || exit 1
 python3 - "$k" <<'PY'
 import sys,re,collections
 k=sys.argv[1]

@@ -2,7 +2,8 @@
 usage: phase_count.py KIND [extra hipcc flags]"""
 import collections, re, subprocess, sys
 kind = sys.argv[1]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+FLAGS = open("/root/repo/quadruped_drake_amd/csrc/hipcc_flags.txt").read().split()
+subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + [
                        "-DWBC_STAMPS", "-DWBC_DEV_ONLY=" + kind, "-S", "--cuda-device-only", "-o", "/tmp/asm/ph.s",
                        "/root/repo/quadruped_drake_amd/csrc/wbc_kernels.hip"] + sys.argv[2:], stderr=subprocess.DEVNULL)
 txt = open("/tmp/asm/ph.s").read().split("\n")
