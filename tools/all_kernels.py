@@ -102,8 +102,11 @@ def report(outdir):
     print("# Round 3: every product kernel under `rocprofv3 --kernel-trace --stats` (MI355X, one profiler run per workload, "
           "`tools/profile_round.sh`)\n")
     print("Average duration = the profiler's `AverageNs` over the run's launches (1 s of clock-ramp launches + 300 timed ones); fraction = "
-          "counted flops per tick x instances / average duration / 78.6 TFLOP/s (FP64 vector peak).  The HIP-event column is the same "
-          "kernel timed by `wbc_time_steps` inside the same process, for agreement.\n")
+          "counted flops per tick x instances / average duration / 78.6 TFLOP/s (FP64 vector peak).  The HIP-event column is the last 300 "
+          "launches timed by `wbc_time_steps` inside the same PROFILED process: launch-to-launch time, i.e. the kernel plus the gap the "
+          "profiler's per-dispatch interception leaves between two launches (an upper bound: 0 - 10 % above the kernel trace depending "
+          "on the box; outside the profiler `bench.py`'s HIP events and the trace agree within 1 %, `hex_bench.json` / `kernel_stats.csv`).  "
+          "Registers / LDS / scratch: of the kernel in the row (`wbc_kernel_info`, `wbc_rollout_kernel_info`).\n")
     print("| workload | kernel | N | calls | rocprofv3 avg µs | min µs | HIP-event µs | iters/tick | VGPR+AGPR | LDS B | scratch B/lane | flops/tick | TFLOP/s | frac of FP64 peak |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for name in WORKLOADS:
