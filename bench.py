@@ -41,8 +41,9 @@ PEAK_HBM_GBS = 8000.0
 
 
 def kernel_src_sha16():
-    """Identity of the kernel sources (csrc/ + the C ABI header): committed counter files carry it, and a counter file that
-    was collected on another build is not mixed with this build's launch time (roofline.issued becomes null instead)."""
+    """Identity of the kernel sources and their code-generation flags (everything under csrc/, hipcc_flags.txt included, + the
+    C ABI header): committed counter files carry it, and a counter file that was collected on another build is not mixed with
+    this build's launch time (roofline.issued becomes null instead)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "quadruped_drake_amd", "csrc")
     for f in sorted(os.listdir(d)) + [os.path.join(ROOT, "include", "wbc.h")]:
