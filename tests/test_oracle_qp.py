@@ -242,3 +242,19 @@ def test_clf_law_literal_qp():
     D = np.diag(((np.arange(n) >= 18) & (np.arange(n) < n - 1)).astype(float))
     xs = scipy_qp(qp["Q"] + p.tiebreak_eps2 * D, qp["c"], qp["Aeq"], qp["beq"], qp["Ain"], qp["bin"])
     assert np.allclose(qp["x"], xs, atol=5e-5 * (1 + np.abs(xs).max())), np.abs(qp["x"] - xs).max()
+
+
+def test_extended_precision_twin_of_the_oracle_agrees_with_it():
+    """oracle/ld: the oracle's own source with every double as x87 long double (tools/lab/truth.py adjudicates HIP-vs-oracle
+    disagreements with it).  Same algorithm, so the two agree to the double build's rounding on small seeded batches."""
+    import numpy as np
+    from oracle import oracle_ld as old
+    from quadruped_drake_amd import workloads
+    for cfg, kind in ((3, "mptc"), (2, "id"), (3, "pc"), (3, "clf"), (4, "mptc")):
+        b = workloads.make_batch(cfg, n=48)
+        t, m_, s = orc.step_batch(kind, orc.model(b["model"]), orc.params(kind), b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
+        tl, ml, sl = old.step_batch(kind, old.model(b["model"]), old.params(kind), b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
+        assert tl.dtype == np.longdouble and (s == 0).all() and (sl == 0).all()
+        r = np.abs(t - tl.astype(float)).max(0) / np.maximum(np.abs(t).max(0), 1e-3)
+        assert r.max() < 1e-6, (kind, cfg, r.max())
+        assert np.allclose(m_, ml.astype(float), rtol=1e-6, atol=1e-7)
