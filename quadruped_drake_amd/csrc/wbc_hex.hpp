@@ -67,6 +67,23 @@ template <int N, class F> WBC_HD void static_for(F f) { static_for_impl(f, std::
 // reduced variable (the slack delta, k = 12) lives on the spare sub-lane 3 of leg 1
 enum { HEX_DELTA_LANE = 7 };
 WBC_HD constexpr int hex_lane(int k) { return k < 12 ? 4 * (k / 3) + (k % 3) : HEX_DELTA_LANE; }
+// Pivot order of the QR factor: slot (whitened coordinate) k belongs to reduced variable hex_piv(k).  The factor is inverted
+// explicitly (J = R^-1, one row per lane, forward substitution), and that is only accurate on every scale when R is GRADED --
+// the eps-sized pivots of the internal-force directions last.  In the natural order (x, y, z of leg 0, leg 1, ...) a 4-contact
+// stand has its six eps-sized pivots interleaved with level-1 sized ones (two point feet span only five wrench directions: y of
+// leg 1 already depends on leg 0) and the body-task part of J is contaminated at 1e-12 x cond: 1e-6 .. 1e-5 on the torques of
+// saturated stands (profiles/r04/accuracy.md).  Order: the three vertical forces z0 z1 z2 (force z, moments x and y), x0 y0
+// (forces x, y), y2 (the yaw moment: left-front and left-hind differ in x) -- six independent wrench columns on any stance --
+// then the rest.  Trots keep their structure (one eps-sized pivot, last or followed by swing variables as before).
+#ifndef WBC_NATURAL_PIVOTS
+WBC_HD constexpr int hex_piv(int k) {
+  constexpr int order[13] = {2, 5, 8, 0, 1, 7, 3, 4, 6, 9, 10, 11, 12};
+  return order[k];
+}
+#else
+WBC_HD constexpr int hex_piv(int k) { return k; }
+#endif
+WBC_HD constexpr int hex_piv_lane(int k) { return hex_lane(hex_piv(k)); }   // lane that owns the k-th pivot column
 
 // Distributed Householder append: fold P dense rows into the upper-triangular factor.
 // Lane hex_lane(c) holds column c: Rcol[12], Acol[P]; the lanes with sub == 3 hold the right-hand side
@@ -79,7 +96,7 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
   qo.template dpp_fence<P>(Acol);
   static_for<NV>([&](auto K) {
     constexpr int k = K;
-    constexpr int piv = hex_lane(k);
+    constexpr int piv = hex_piv_lane(k);
     // three accumulators, the terms in blocks of <= 15 fused ops (one asm statement each: Q::dot_bc)
     double ta = 0.0, tb = 0.0, tc = 0.0;
     {
@@ -352,6 +369,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
     for (int k = 0; k < NV; k++) mk[k] = (k >= q) ? 1.0 : 0.0;
   }
+  bool dropped = false, wave_dropped = false;   // this robot / any robot of the wavefront has dropped a row (the second: wave-uniform)
   WBC_GI_TIMERS;
   for (int trip = 0; generic && trip < maxit; trip++) {
     WBC_GI_T0();
@@ -503,6 +521,8 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
     for (int k = 0; k < NV; k++) x[k] = dm[k];
     const bool anyd = qo.wave_any(drop);
+    dropped = dropped || drop;
+    wave_dropped = wave_dropped || anyd;
     if (GIV && anyd) {
       // Drop by Givens rotations computed from the IMAGES (the task-space laws: their stands are where the accuracy of the
       // cheaper W-row reflection below shows, profiles/r03/soak.md): the images stay triangular in list order; removing the
@@ -713,6 +733,50 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     WBC_GI_T(4);   // reflection
   }
   WBC_GI_TEND();
+  // ---- A robot that has DROPPED a row gets its solution from the rotated right-hand side instead of the accumulated steps:
+  //     z = J[:, q:] (y[q:] - sum over the active rows of u_a D_a[q:]),   u_a = W_a . y[:q]  (the multipliers, fresh).
+  // y = Q'b rides through every reflection in the row slots of lane (0, 3), which owns no row of J.  The first term is the
+  // projection in exact arithmetic; the second is the first-order correction for what the active images have LEFT in the free
+  // slots (a drop frees its slot through the blocking row's W row, an inverse only to eps x cond: the remaining images keep
+  // ~1e-13 of their norm there, and a residual in a body-task slot, where y ~ 300, is amplified by the 1e4 columns of J).
+  // Where the digits went was located in round 3 (profiles/r03/truth.md); what closes it was found in round 4
+  // (profiles/r04/accuracy.md): on saturated 4-contact stands the accumulated z is off by up to 2e-6 (ID) / 6e-6 (MPTC) of the exact
+  // projection on the final active set, the evaluated one alone just as much, this one by 5e-9 -- the level of a fresh QR of the
+  // active images.  Robots that never dropped keep the accumulated z (bit-identical to round 3, trots: no cost); the code runs
+  // when any robot of the wavefront has dropped, a robot's result does not depend on its wave-mates.
+#ifndef WBC_NO_DROP_REFINE
+  if (generic && wave_dropped) {
+    // inhomogeneous rows (dense row: n.z = vc pc_inv;  torque row: (sig Tn).z = -bt - sig t0n) put g = sum beta_a W_a into the used slots
+    double yk[NV], g[NV];
+    const double b_pc = (PC && act_pc) ? vc * pc_inv : 0.0, b_t = (TB && act_t) ? -(bt + sig_t * t0n) : 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      yk[k] = qo.bcast16(Jr[k], 3);
+      g[k] = 0.0;
+      if (TB) g[k] = qo.sum16(b_t * Wt[k]);
+      if (PC) g[k] = fmad(b_pc, Wpc[k], g[k]);
+    }
+    double nu = 0.0, nu_pc = 0.0, nu_t = 0.0, zr = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const double yg = (PC || TB) ? yk[k] - g[k] : yk[k];
+      nu = fmad(Wr[k], yg, nu);
+      if (PC) nu_pc = fmad(Wpc[k], yg, nu_pc);
+      if (TB) nu_t = fmad(Wt[k], yg, nu_t);
+    }
+    nu = act_h ? nu : 0.0;
+    if (PC) nu_pc = act_pc ? nu_pc : 0.0;
+    if (TB) nu_t = act_t ? sig_t * nu_t : 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      double c = qo.sum16(TB ? fmad(nu_t, Dt[k], nu * Dh[k]) : nu * Dh[k]);
+      if (PC) c = fmad(nu_pc, Dpc[k], c);
+      const double yh = mk[k] * (yk[k] - c);
+      zr = fmad(Jr[k], (PC || TB) ? yh + g[k] : yh, zr);
+    }
+    z = dropped ? zr : z;
+  }
+#endif
   *iters_out = iters;
   if (!done && status == ST_OK) status = ST_ITER;
   return status;
@@ -1120,8 +1184,8 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     else { dval = 0.0; drhs = 0.0; }
 #pragma unroll
     for (int k = 0; k < NZ; k++) {
-      const double rk = (KIND == KIND_MPTC || KIND == KIND_PC) ? 0.0 : qo.bcast16(drhs, hex_lane(k));   // task-space laws: no right-hand side on the diagonal rows
-      Rcol[k] = colv ? ((hex_lane(k) == h) ? dval : 0.0) : (cold ? 0.0 : rk);
+      const double rk = (KIND == KIND_MPTC || KIND == KIND_PC) ? 0.0 : qo.bcast16(drhs, hex_piv_lane(k));   // task-space laws: no right-hand side on the diagonal rows
+      Rcol[k] = colv ? ((hex_piv_lane(k) == h) ? dval : 0.0) : (cold ? 0.0 : rk);   // slot k = variable hex_piv(k)
     }
     if (KIND == KIND_CLF) Rcol[NV - 1] = cold ? sqrt(2.0 * 1000.0) : 0.0;   // w_delta delta^2 = 1/2 (sqrt(2 w) delta)^2  (:73,:206)
   };
@@ -1418,12 +1482,12 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
   {
     const double rown = [&] { double x = 0.0;
 #pragma unroll
-      for (int k = 0; k < NV; k++) x = (hex_lane(k) == h) ? Rcol[k] : x;
+      for (int k = 0; k < NV; k++) x = (hex_piv_lane(k) == h) ? Rcol[k] : x;
       return x; }();
     const double inv_own = fast_rcp(rown);
     double invd[NV];
 #pragma unroll
-    for (int c = 0; c < NV; c++) invd[c] = qo.bcast16(inv_own, hex_lane(c));
+    for (int c = 0; c < NV; c++) invd[c] = qo.bcast16(inv_own, hex_piv_lane(c));
     // pivot range over the column lanes (1/|R_cc|: max <-> min swap)
     const double ainv = fabs(inv_own);
     const double rmax = qo.max16((colv || cold) ? ainv : 0.0), rmin = qo.min16((colv || cold) ? ainv : HEX_NONE);
@@ -1439,8 +1503,10 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
       *iters_out = 0;
       return status;
     }
-    // my row index rr = 3*l + sb (column lanes; 12 on the delta lane).  J[rr][c] = (delta_rr,c - sum_{k<c} J[rr][k] R[k][c]) / R[c][c]
-    const int rr = cold ? NZ : 3 * l + sb;
+    // my row index rr = the slot of my variable 3*l + sb (column lanes; 12 on the delta lane).  J[rr][c] = (delta_rr,c - sum_{k<c} J[rr][k] R[k][c]) / R[c][c]
+    int rr = NZ;
+#pragma unroll
+    for (int k = 0; k < NZ; k++) rr = (hex_piv_lane(k) == h) ? k : rr;
     double zacc = 0.0;
     qo.template dpp_fence<NV>(Rcol);
     static_for<NV>([&](auto CC) {
@@ -1448,15 +1514,21 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
       double s = ((colv || cold) && c == rr) ? -1.0 : 0.0;   // the NEGATIVE of the row entry accumulates (no per-term negation)
       double sb2 = 0.0, sc2 = 0.0;                            // three accumulators: no fused op reads the result of the two before it
       static_for<c>([&](auto KK) {
-        if constexpr (KK % 3 == 0) s = qo.template fma_bc<hex_lane(c)>(s, Rcol[KK], Jr[KK]);
-        else if constexpr (KK % 3 == 1) sb2 = qo.template fma_bc<hex_lane(c)>(sb2, Rcol[KK], Jr[KK]);
-        else sc2 = qo.template fma_bc<hex_lane(c)>(sc2, Rcol[KK], Jr[KK]);
+        if constexpr (KK % 3 == 0) s = qo.template fma_bc<hex_piv_lane(c)>(s, Rcol[KK], Jr[KK]);
+        else if constexpr (KK % 3 == 1) sb2 = qo.template fma_bc<hex_piv_lane(c)>(sb2, Rcol[KK], Jr[KK]);
+        else sc2 = qo.template fma_bc<hex_piv_lane(c)>(sc2, Rcol[KK], Jr[KK]);
       });
       if (c > 2) s += sb2 + sc2; else if (c > 1) s += sb2;
       Jr[c] = -s * invd[c];
       zacc = qo.template fma_bc<3>(zacc, Rcol[c], Jr[c]);   // rhs column after the appends (lane (0,3))
     });
     z = zacc;
+    // lane (0, 3) owns no row of J: its row slots carry y = Q'b (the right-hand-side column after the append) through the active
+    // set's reflections, for the evaluation of z after a drop (hex_gi)
+#ifndef WBC_NO_DROP_REFINE
+#pragma unroll
+    for (int c = 0; c < NV; c++) Jr[c] = (h == 3) ? Rcol[c] : Jr[c];
+#endif
   }
   WBC_STAMP(15);
   WBC_HCUT_AT(6, z + Jr[0] + Jr[5] + Jr[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
