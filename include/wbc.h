@@ -61,8 +61,11 @@ extern "C" {
 /* wbc_create flags */
 #define WBC_DEVICE_PTRS 0u /* wbc_step receives device pointers (default) */
 #define WBC_HOST_PTRS 1u   /* wbc_step receives host pointers; staged through handle-owned buffers (n <= 64: one pinned,
-                              device-mapped block the kernel reads and writes directly, no copy calls).  As with device
-                              pointers the outputs are valid after wbc_sync (a later wbc_step on the handle collects them too) */
+                              device-mapped block the kernel reads and writes directly, no copy calls).  The OUTPUT arrays of a
+                              wbc_step must stay valid until the outputs have been delivered, and only the library delivers
+                              them: wbc_sync, or the next wbc_step / wbc_set_stream / wbc_destroy on the handle (each first
+                              collects a pending result).  Waiting on the stream or on an event of one's own does NOT: for
+                              n <= 64 the copy into the caller's arrays is host code that runs inside those calls */
 
 /* Kinematic tree + inertias, as produced by tools/compile_model.py from the reference's URDFs
  * (models/mini_cheetah/mini_cheetah_mesh.urdf, models/anymal_b_simple_description/urdf/anymal_drake.urdf):
@@ -87,7 +90,7 @@ typedef struct wbc_handle_s* wbc_handle;
 typedef struct wbc_traj_s* wbc_traj; /* stored trunk trajectory, see the end of this header */
 
 /* End-of-rollout statistics accumulated on the device by wbc_step (one small vector per GPU;
- * reduced across GPUs by the host with one RCCL all-reduce). */
+ * reduced across GPUs with ONE RCCL all-gather of wbc_stats_pack vectors and wbc_stats_reduce, below). */
 typedef struct {
   double ticks;          /* instances stepped */
   double status_nonzero; /* instances with status != 0 */
@@ -144,6 +147,14 @@ int wbc_time_steps_each(wbc_handle h, int steps, int n, int ld, const double* q,
 /* Statistics since the last reset (blocks until the stream is idle). */
 int wbc_stats_get(wbc_handle h, wbc_stats* out);
 int wbc_stats_reset(wbc_handle h);
+/* The one exchange between GPUs (north_star: "RCCL only to gather end-of-rollout statistics"), for a caller that brings its own
+ * collective: wbc_stats_pack = wbc_stats_get as a flat vector of WBC_NSTAT doubles in the field order of the wbc_stats struct; it blocks like wbc_stats_get --
+ * the send buffer of ONE ncclAllGather(sendbuf, recvbuf, WBC_NSTAT, ncclDouble, comm, stream) per rank; wbc_stats_reduce folds the
+ * `world` gathered vectors (rank-major, world * WBC_NSTAT doubles, host memory) into one wbc_stats: every field is summed except
+ * tau_abs_max, which is the maximum.  Pure host arithmetic, no handle, no GPU; world >= 1. */
+#define WBC_NSTAT 22
+int wbc_stats_pack(wbc_handle h, double* out22);
+int wbc_stats_reduce(const double* gathered, int world, wbc_stats* out);
 
 /* Closed-loop rollouts.  If set (device pointer, [18][ld], same ld as wbc_step),
  * every wbc_step also writes the generalized accelerations vd of its QP solution (rows in the
@@ -213,44 +224,6 @@ int wbc_traj_destroy(wbc_traj t);
  * (device) on `hip_stream` (NULL = default stream).  Asynchronous. */
 int wbc_traj_lookup(wbc_traj t, void* hip_stream, int n, int ld, const double* time, double* targets,
                     uint8_t* contact_mask);
-
-/* ------------------------------------------------------------------------------------------
- * The robot-side wire format of the reference's use_lcm path (controllers/basic_controller.py:52-61,79-87,289-314):
- * `robot_state_control_lcmt` (lcm_types/robot_state_control_lcmt.lcm: float q[19], v[18], tau[12]) -- 204 bytes,
- * 8-byte fingerprint rotl1(0xbe14089c923ad667) then 49 big-endian IEEE floats
- * (lcm_types/cheetahlcm/robot_state_control_lcmt.py:28-79).  States arrive on "robot_current_state" in the plant's
- * own joint order (exactly the rows wbc_step takes with q_perm); torques leave on "robot_control_input" as
- * (S'u)[-12:] -- the actuator-order torques re-indexed to the plant's joint order (basic_controller.py:310-313),
- * q and v of that message left zero. */
-#define WBC_ROBOT_STATE_BYTES 204
-typedef struct {
-  float q[19], v[18], tau[12];
-} wbc_robot_state;
-/* host, one message: 0 on success; -1 short buffer / null; -3 fingerprint mismatch ("Decode error", :51-52) */
-int wbc_robot_state_decode(const uint8_t* buf, size_t len, wbc_robot_state* out);
-/* host, one message: bytes written (204) or -1 */
-int wbc_robot_state_encode(const wbc_robot_state* in, uint8_t* buf, size_t cap);
-/* device, batched: n messages back to back in `msgs` (device, 4-byte aligned) -> q[19][ld], v[18][ld] (float -> double
- * is exact); ok[i] (nullable) = 1 decoded / 0 fingerprint mismatch (that robot's columns are left untouched).
- * Asynchronous on `hip_stream`. */
-int wbc_robot_states_unpack(int device, void* hip_stream, int n, int ld, const uint8_t* msgs, double* q, double* v,
-                            uint8_t* ok);
-/* device, batched: tau[12][ld] in ACTUATOR order (what wbc_step wrote) -> n "robot_control_input" messages.
- * q_perm / act_perm: host int[12], the handle's model permutations (NULL = identity):
- * message.tau[q_perm[act_perm[k]]] = (float) tau[k].  Asynchronous on `hip_stream`. */
-int wbc_robot_controls_pack(int device, void* hip_stream, int n, int ld, const double* tau, const int* q_perm,
-                            const int* act_perm, uint8_t* msgs);
-
-/* ------------------------------------------------------------------------------------------
- * The reference's joint-space PD law (control method "B": BasicController.ControlLaw, controllers/basic_controller.py:322-352),
- * batched and stateless: tau_v = -Kp N+(q)(q - q_nom) - Kd v, u = clip(S tau_v, -u_max, u_max).  S selects the twelve joint rows,
- * where N+ is the identity, so u[k] = clip(-(kp (q_j - q_nom_j)) - kd v_j) with j = the plant index of the joint actuator k drives
- * (j = q_perm[act_perm[k]]); evaluated without fused multiply-add, i.e. bit for bit what the reference's numpy computes.
- * q[19][ld], v[18][ld], tau[12][ld] (actuator order) are device pointers; q_nom19 is a HOST array in the plant's own joint order
- * (NULL = the reference's literal: base at (0, 0, 0.3), every leg (0, -0.8, 1.6)); the reference's gains are kp 30, kd 1.5, u_max 150.
- * q_perm / act_perm: host int[12], NULL = identity.  Asynchronous on `hip_stream`. */
-int wbc_pd_step(int device, void* hip_stream, int n, int ld, const double* q, const double* v, const double* q_nom19,
-                double kp, double kd, double u_max, const int* q_perm, const int* act_perm, double* tau);
 
 #ifdef __cplusplus
 }

@@ -45,9 +45,14 @@ def pack_trunk_input(trunk_data):
 
 
 class SolverError(AssertionError):
-    """Mirrors `assert result.is_success()` (inverse_dynamics_controller.py:224).  args = (text, status, tau): for status 3
-    (MPTC / PC with a nearly straight knee: the law's own inv(J M^-1 J') is ill-conditioned) the torques were computed and
-    ride along, but nothing vouches for them."""
+    """Mirrors `assert result.is_success()` (inverse_dynamics_controller.py:224).  args = (text, status, tau).  Raised for
+    status 1 (iteration cap) and 2 (singular / infeasible).  Status 3 (MPTC / PC with a nearly straight knee: the law's own
+    inv(J M^-1 J') is ill-conditioned) is a solved tick -- the reference's assert passes there and it applies the torques -- so
+    the mirror returns them with an IllConditionedWarning and `last_status = 3`; `strict=True` turns that into this error too."""
+
+
+class IllConditionedWarning(RuntimeWarning):
+    """A tick of a task-space law with |sin(knee)| < 1e-4 on a leg (status 3): torques computed, not vouched for."""
 
 
 STATUS_TEXT = {1: "iteration cap", 2: "singular / infeasible: torques and accelerations are zero",
@@ -58,7 +63,9 @@ class BatchedController:
     kind = None
 
     def __init__(self, model="mini_cheetah", max_batch=4096, device=0, params=None, host_ptrs=False,
-                 q_perm=None, act_perm=None, use_torch_stream=True):
+                 q_perm=None, act_perm=None, use_torch_stream=True, strict=False):
+        self.strict = bool(strict)      # ControlLaw: raise on status 3 as well (default: warn and return the torques)
+        self.last_status = 0
         self.table = load_model(model) if isinstance(model, str) else model
         self.max_batch = int(max_batch)
         self.device = int(device)
@@ -294,7 +301,8 @@ class BatchedController:
     # -- single-robot convenience with the reference's signature --------------------------
     def ControlLaw(self, q, v, trunk_data):
         """controllers/*_controller.py ControlLaw(context, q, v) for ONE robot given the planner dict.
-        Raises SolverError on a non-zero status, like the reference's assert."""
+        Raises SolverError on status 1 / 2, like the reference's assert; status 3 (ill-conditioned, torques written) warns
+        and returns the torques, as the reference -- whose solver reports success there -- would apply them."""
         t, mask = pack_trunk_input(trunk_data)
         qq = np.asarray(q, float).reshape(19, 1); vv = np.asarray(v, float).reshape(18, 1)
         if self.host_ptrs:
@@ -309,7 +317,11 @@ class BatchedController:
                              torch.tensor([mask], dtype=torch.uint8, device=dev))
             self.sync()
             tau, met, st = outs[0][:, 0].cpu().numpy(), outs[1][:, 0].cpu().numpy(), int(outs[2][0])
-        if st != 0:
+        self.last_status = st
+        if st == 3 and not self.strict:
+            import warnings
+            warnings.warn("whole-body QP tick flagged with status 3 (%s)" % STATUS_TEXT[3], IllConditionedWarning, stacklevel=2)
+        elif st != 0:
             raise SolverError("whole-body QP failed with status %d (%s)" % (st, STATUS_TEXT.get(st, "unknown")), st, tau)
         self.V, self.err, self.res, self.Vdot = (float(x) for x in met)
         return tau

@@ -185,7 +185,7 @@ WBC_HD int hex_key_index(double k) {
 template <class Q, bool PC, int NV = NZ, bool TB = false, bool GAIN = false, bool GIV = false>
 WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, double inv_s, int* iters_out,
                   double vrow_own = 0.0, double vc = 0.0, double pc_inv = 0.0, const double* Tn = nullptr,
-                  double t0n = 0.0, double bt = -1.0) {
+                  double t0n = 0.0, double bt = -1.0, bool deep = true) {
   const int sb = h & 3;
   const bool pc = PC && pc_inv > 0.0;
   WBC_GI_STAT(if (g_gi_dump) { double* o = g_gi_dump + h * 16; for (int k = 0; k < NV && k < 13; k++) o[k] = Jr[k]; o[13] = z; o[14] = mu_n; o[15] = ct ? inv_s : 0.0; });
@@ -369,7 +369,8 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
     for (int k = 0; k < NV; k++) mk[k] = (k >= q) ? 1.0 : 0.0;
   }
-  bool dropped = false, wave_dropped = false;   // this robot / any robot of the wavefront has dropped a row (the second: wave-uniform)
+  bool dropped = false, wave_dropped = false;   // this (deep) robot has dropped a row / the wavefront has a deep robot and a drop (wave-uniform)
+  const bool wave_deep = generic && qo.wave_any(deep);
   WBC_GI_TIMERS;
   for (int trip = 0; generic && trip < maxit; trip++) {
     WBC_GI_T0();
@@ -521,8 +522,8 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
     for (int k = 0; k < NV; k++) x[k] = dm[k];
     const bool anyd = qo.wave_any(drop);
-    dropped = dropped || drop;
-    wave_dropped = wave_dropped || anyd;
+    dropped = dropped || (drop && deep);
+    wave_dropped = wave_dropped || (anyd && wave_deep);
     if (GIV && anyd) {
       // Drop by Givens rotations computed from the IMAGES (the task-space laws: their stands are where the accuracy of the
       // cheaper W-row reflection below shows, profiles/r03/soak.md): the images stay triangular in list order; removing the
@@ -742,8 +743,10 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   // Where the digits went was located in round 3 (profiles/r03/truth.md); what closes it was found in round 4
   // (profiles/r04/accuracy.md): on saturated 4-contact stands the accumulated z is off by up to 2e-6 (ID) / 6e-6 (MPTC) of the exact
   // projection on the final active set, the evaluated one alone just as much, this one by 5e-9 -- the level of a fresh QR of the
-  // active images.  Robots that never dropped keep the accumulated z (bit-identical to round 3, trots: no cost); the code runs
-  // when any robot of the wavefront has dropped, a robot's result does not depend on its wave-mates.
+  // active images.  `deep` = the robot has three or four feet on the ground, i.e. three or six internal-force directions: with two
+  // (every trot) there is one, and the robots of a trot batch that drop a row are within 1e-12 of the extended-precision oracle
+  // either way (measured on 130 of them).  Robots that never dropped keep the accumulated z; the code runs when any deep robot of
+  // the wavefront has dropped, and a robot's result does not depend on its wave-mates.
 #ifndef WBC_NO_DROP_REFINE
   if (generic && wave_dropped) {
     // inhomogeneous rows (dense row: n.z = vc pc_inv;  torque row: (sig Tn).z = -bt - sig t0n) put g = sum beta_a W_a into the used slots
@@ -1535,20 +1538,21 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
   // ---------------- friction rows (+ the optional torque box)
   int iters = 0;
   {
+    const bool deep = ((mask & 1u) + ((mask >> 1) & 1u) + ((mask >> 2) & 1u) + ((mask >> 3) & 1u)) >= 3u;   // >= 3 internal-force directions (hex_gi)
     double s, rs;   // sqrt(1 + mu^2) and its reciprocal from one hardware seed
     fast_sqrt_rsq(1.0 + mu * mu, s, rs);
     (void)s;
     int st;
     if (KIND == KIND_PC) {
-      st = hex_gi<Q, true, NV, TB, false, WBC_GIVENS_DROPS != 0>(qo, h, ct, Jr, z, mu * rs, rs, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt);
+      st = hex_gi<Q, true, NV, TB, false, WBC_GIVENS_DROPS != 0>(qo, h, ct, Jr, z, mu * rs, rs, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt, deep);
     } else if (KIND == KIND_CLF) {
       // the CLF row  g . [z; delta] - ub <= 0  is the dense row of the active set (index 16), like PC's Vdot row
-      st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu * rs, rs, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt);
+      st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu * rs, rs, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt, deep);
     } else {
 #ifndef WBC_GAIN_ID
 #define WBC_GAIN_ID 0
 #endif
-      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC || (WBC_GAIN_ID && KIND == KIND_ID)) && !TB, (WBC_GIVENS_DROPS != 0) && KIND == KIND_MPTC>(qo, h, ct, Jr, z, mu * rs, rs, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt);
+      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC || (WBC_GAIN_ID && KIND == KIND_ID)) && !TB, (WBC_GIVENS_DROPS != 0) && KIND == KIND_MPTC>(qo, h, ct, Jr, z, mu * rs, rs, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt, deep);
     }
     if (st != ST_OK) status = st;
     if (status == ST_OK && illc) status = ST_ILLCOND;

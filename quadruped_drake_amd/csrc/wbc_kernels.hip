@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "../../include/wbc.h"
+#include "../../include/wbc_extras.h"
 #ifdef WBC_STAMPS
 __device__ unsigned long long g_wbc_stamps[16 * 4096];
 #endif
@@ -733,6 +734,7 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
 int wbc_destroy(wbc_handle h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
+  if (h->zpend.active) (void)zc_finish(h);   // a small-batch host-pointer tick still pending: its outputs are delivered, not dropped
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   void* bufs[] = {h->d_model, h->d_params, h->d_stats, h->s_q, h->s_v, h->s_tg, h->s_mu, h->s_ms,
                   h->s_tau, h->s_met, h->s_mask, h->s_status};
@@ -934,6 +936,29 @@ int wbc_stats_get(wbc_handle h, wbc_stats* out) {
   double mx; memcpy(&mx, &s.tau_abs_max_bits, 8);
   out->tau_abs_max = mx;
   for (int k = 0; k < 16; k++) out->mask_count[k] = s.mask_count[k];
+  return 0;
+}
+
+int wbc_stats_pack(wbc_handle h, double* out22) {
+  if (!h || !out22) return misuse("wbc_stats_pack: null argument");
+  static_assert(sizeof(wbc_stats) == WBC_NSTAT * sizeof(double), "wbc_stats is WBC_NSTAT doubles in declaration order");
+  wbc_stats s;
+  const int rc = wbc_stats_get(h, &s);
+  if (rc) return rc;
+  memcpy(out22, &s, sizeof s);
+  return 0;
+}
+
+int wbc_stats_reduce(const double* gathered, int world, wbc_stats* out) {
+  if (!gathered || !out || world < 1) return misuse("wbc_stats_reduce: null argument or world < 1");
+  double acc[WBC_NSTAT];
+  for (int k = 0; k < WBC_NSTAT; k++) acc[k] = gathered[k];
+  constexpr int MAX_FIELD = offsetof(wbc_stats, tau_abs_max) / sizeof(double);
+  for (int r = 1; r < world; r++) {
+    const double* g = gathered + (size_t)r * WBC_NSTAT;
+    for (int k = 0; k < WBC_NSTAT; k++) acc[k] = (k == MAX_FIELD) ? (g[k] > acc[k] ? g[k] : acc[k]) : acc[k] + g[k];
+  }
+  memcpy(out, acc, sizeof acc);
   return 0;
 }
 

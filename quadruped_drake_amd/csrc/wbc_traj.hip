@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "../../include/wbc.h"
+#include "../../include/wbc_extras.h"
 #include "wbc_traj_dev.hpp"
 
 // the one thread-local message buffer behind wbc_last_error() (defined in wbc_kernels.hip)

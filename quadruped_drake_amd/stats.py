@@ -2,14 +2,13 @@
 
 The robot-instance batch shards embarrassingly: rank g owns instances [g*N/W, (g+1)*N/W) and no
 instance reads another's state, so there is no data-path collective.  The only exchange is one
-all-gather of a 22-double statistics vector at the end of a rollout (reduced locally: SUM fields and one MAX field)
+all-gather of a 22-double statistics vector at the end of a rollout (the wbc_stats_pack layout of include/wbc.h, reduced
+by wbc_stats_reduce: sums and one maximum; a C caller does the same with its own ncclAllGather)
 -- RCCL over xGMI on the GPU box (backend "nccl"), gloo in the CPU tests.  At < 200 B the message
 is latency-bound; link bandwidth is irrelevant.
 """
 import numpy as np
 
-SUM_FIELDS = ["ticks", "status_nonzero", "iters_sum", "tau_abs_sum", "err_sum"]
-MAX_FIELDS = ["tau_abs_max"]
 
 
 def shard_range(n_total, rank, world):
@@ -30,34 +29,47 @@ def shard_batch(batch, rank, world):
     return out
 
 
-def pack(stats):
-    s = np.array([stats[k] for k in SUM_FIELDS] + list(stats["mask_count"]), dtype=np.float64)
-    m = np.array([stats[k] for k in MAX_FIELDS], dtype=np.float64)
-    return s, m
+FIELDS = ["ticks", "status_nonzero", "iters_sum", "tau_abs_sum", "tau_abs_max", "err_sum"]   # wbc_stats, declaration order (include/wbc.h)
+NSTAT = 22
 
 
-def unpack(s, m):
-    out = {k: float(s[i]) for i, k in enumerate(SUM_FIELDS)}
-    out["mask_count"] = [float(x) for x in s[len(SUM_FIELDS):]]
-    out.update({k: float(m[i]) for i, k in enumerate(MAX_FIELDS)})
+def to_vector(stats):
+    """The wbc_stats_pack vector (WBC_NSTAT doubles in the field order of wbc_stats) of a statistics dict."""
+    return np.array([stats[k] for k in FIELDS] + list(stats["mask_count"]), dtype=np.float64)
+
+
+def from_vector(vec):
+    out = {k: float(vec[i]) for i, k in enumerate(FIELDS)}
+    out["mask_count"] = [float(x) for x in vec[len(FIELDS):NSTAT]]
     return out
 
 
+def reduce_vectors(gathered):
+    """wbc_stats_reduce of the C ABI on `world` gathered vectors ([world, 22]): the reduction a C caller with its own
+    ncclAllGather runs -- the Python mirror goes through the same function."""
+    import ctypes as C
+    from . import _lib
+    g = np.ascontiguousarray(gathered, dtype=np.float64).reshape(-1, NSTAT)
+    out = _lib.WbcStats()
+    _lib.check(_lib.lib().wbc_stats_reduce(g.ctypes.data_as(_lib.c_double_p), int(g.shape[0]), C.byref(out)))
+    d = {k: float(getattr(out, k)) for k in FIELDS}
+    d["mask_count"] = [float(x) for x in out.mask_count]
+    return d
+
+
 def all_gather_stats(stats, device=None):
-    """ONE collective: gather every rank's 22-double vector, reduce (sum / max) locally.
+    """ONE collective: gather every rank's 22-double vector (wbc_stats_pack layout), reduce with wbc_stats_reduce.
     Returns (reduced dict, per-rank list of dicts, world size seen by the process group)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return dict(stats), [dict(stats)], 1
     # an initialised group of ONE rank still goes through the collective (bench.py --force-pg: the RCCL path on a one-GPU box)
-    s, m = pack(stats)
-    t = torch.tensor(np.concatenate([s, m]), dtype=torch.float64, device=device)
+    t = torch.tensor(to_vector(stats), dtype=torch.float64, device=device)
     parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(parts, t)
     a = torch.stack(parts).cpu().numpy()
-    per_rank = [unpack(a[r, :len(s)], a[r, len(s):]) for r in range(a.shape[0])]
-    return unpack(a[:, :len(s)].sum(0), a[:, len(s):].max(0)), per_rank, dist.get_world_size()
+    return reduce_vectors(a), [from_vector(a[r]) for r in range(a.shape[0])], dist.get_world_size()
 
 
 def all_reduce_stats(stats, device=None):

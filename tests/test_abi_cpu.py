@@ -15,12 +15,45 @@ def test_library_loads_and_exports_every_declared_symbol():
         import __graft_entry__ as g
         g.build()
     l = _lib.lib()
-    hdr = open(os.path.join(ROOT, "include", "wbc.h")).read()
+    import glob
+    hdr = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(ROOT, "include", "*.h"))))
     declared = sorted(set(re.findall(r"\b(wbc_[a-z_]+)\s*\(", hdr)))
     assert declared == sorted(_lib.SYMBOLS), (declared, sorted(_lib.SYMBOLS))
     for s in declared:
         assert hasattr(l, s), s
     assert l.wbc_version() >= 100
+
+
+def test_the_boundary_header_is_the_controller_interface_only():
+    """include/wbc.h = the reference's controller interface (+ the widened rows of SURVEY 8f); the frozen out-of-scope exports
+    (PD law, robot-side wire format) live in include/wbc_extras.h."""
+    main = open(os.path.join(ROOT, "include", "wbc.h")).read()
+    extras = open(os.path.join(ROOT, "include", "wbc_extras.h")).read()
+    for s in ("wbc_pd_step", "wbc_robot_state_decode", "wbc_robot_state_encode", "wbc_robot_states_unpack", "wbc_robot_controls_pack"):
+        assert s not in main and s in extras, s
+    for s in ("wbc_create", "wbc_step", "wbc_sync", "wbc_destroy", "wbc_stats_get", "wbc_stats_pack", "wbc_stats_reduce", "wbc_last_error"):
+        assert s in main, s
+
+
+def test_stats_reduce_folds_gathered_vectors_without_a_gpu():
+    """wbc_stats_reduce: the host half of the one collective (a C caller brings its own ncclAllGather of wbc_stats_pack vectors):
+    sums everywhere, the maximum on tau_abs_max; equal to the Python mirror's reduction (quadruped_drake_amd/stats.py)."""
+    from quadruped_drake_amd import _lib, stats
+    l = _lib.lib()
+    rng = np.random.default_rng(3)
+    world = 5
+    g = rng.uniform(0.0, 100.0, (world, 22))
+    out = _lib.WbcStats()
+    assert l.wbc_stats_reduce(g.ctypes.data_as(_lib.c_double_p), world, C.byref(out)) == 0
+    got = np.array([out.ticks, out.status_nonzero, out.iters_sum, out.tau_abs_sum, out.tau_abs_max, out.err_sum] + list(out.mask_count))
+    want = g.sum(0); want[4] = g[:, 4].max()
+    assert np.allclose(got, want, rtol=1e-15)
+    per_rank = [stats.from_vector(g[r]) for r in range(world)]
+    red = stats.reduce_vectors(g)
+    assert red["tau_abs_max"] == g[:, 4].max() and abs(red["ticks"] - g[:, 0].sum()) < 1e-9 and red["mask_count"][15] == pytest.approx(g[:, 21].sum())
+    assert per_rank[2]["err_sum"] == g[2, 5]
+    assert l.wbc_stats_reduce(None, 1, C.byref(out)) < 0 and l.wbc_stats_reduce(g.ctypes.data_as(_lib.c_double_p), 0, C.byref(out)) < 0
+    assert l.wbc_stats_pack(None, g.ctypes.data_as(_lib.c_double_p)) < 0
 
 
 def test_params_default_matches_reference_literals():

@@ -1,6 +1,9 @@
 """-m gpu: the HIP path, called through the C ABI (include/wbc.h), against the oracle and the
-committed golden vectors.  Tolerance: north_star asks for torques within 1e-4 relative of the CPU
-reference; the measured error is ~1e-7 (ill-conditioning of the eps2 tie-break)."""
+committed golden vectors.  north_star asks for torques within 1e-4 relative of the CPU reference (TOL); the tests hold
+each configuration to what it actually delivers instead (profiles/r04/soak.md, truth.md: trots 2e-7 against the
+double-precision oracle -- mostly the oracle's own rounding -- saturated 4-contact stands 6e-7, PC stands 4e-6 where the
+oracle itself is 4e-6 from its extended-precision twin), so that a regression of two orders of magnitude on the headline
+configuration cannot hide under the bar, and the stands are tested at the depth where outliers live."""
 import glob
 import os
 
@@ -9,7 +12,15 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-TOL = 1e-4
+TOL = 1e-4         # the north-star bar: odd states (all 16 masks, torque boxes on stands, permuted plants, singular sweeps)
+TOL_TROT = 1e-6    # configs 3, 4, 5 (2-contact trots), every law: measured <= 2e-7 over 33 M instances
+TOL_STAND = 1e-5   # config 2 (4-contact stands far outside their pyramids): measured <= 6e-7 (ID, MPTC) / 4.2e-6 (PC) over 4 M
+
+
+def tol_for(cfg):
+    return TOL_STAND if cfg == 2 else TOL_TROT
+
+
 GOLD = sorted(f for f in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
               if os.path.basename(f).startswith(("cfg", "masks16")))   # the tick fixtures of make_golden.py
 
@@ -61,7 +72,9 @@ def test_gpu_matches_golden_vectors(path):
     g = load_gold(path)
     tau, met, st, _ = gpu_step(g["kind"], g["model"], g["q"], g["v"], g["targets"], g["mask"], g["mu"], g["mass_scale"])
     assert np.array_equal(st, g["status"])
-    assert rel_err(tau, g["tau"]).max() < TOL
+    name = os.path.basename(path)
+    tol = TOL_STAND if name.startswith(("cfg2", "masks16")) else TOL_TROT      # masks16: every contact pattern, stands included
+    assert rel_err(tau, g["tau"]).max() < tol, rel_err(tau, g["tau"]).max()
     assert np.allclose(met, g["metrics"], rtol=1e-5, atol=1e-6)
 
 
@@ -76,7 +89,7 @@ def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n):
     tau_o, met_o, st_o = orc.step_batch(kind, m, p, b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
     assert (st == 0).all() and (st_o == 0).all()
     r = rel_err(tau, tau_o)
-    assert r.max() < TOL, r.max()
+    assert r.max() < tol_for(cfg), r.max()
     assert np.median(r) < 1e-9
     assert np.allclose(met, met_o, rtol=1e-5, atol=1e-6)
     # device-side end-of-rollout statistics agree with the outputs
@@ -94,7 +107,7 @@ def test_ragged_batch_sizes(n):
     tau, met, st, _ = gpu_step("mptc", b["model"], b["q"], b["v"], b["targets"], b["mask"], max_batch=256)
     tau_o, _, _ = orc.step_batch("mptc", orc.model(b["model"]), orc.params("mptc"), b["q"], b["v"], b["targets"], b["mask"])
     assert tau.shape == (12, n) and (st == 0).all()
-    assert rel_err(tau, tau_o).max() < TOL
+    assert rel_err(tau, tau_o).max() < TOL_TROT
 
 
 def test_empty_batch_and_misuse():
@@ -277,7 +290,7 @@ def test_single_robot_control_law_mirrors_reference_signature():
 
 def test_ill_conditioned_ticks_are_reported_not_hidden():
     """MPTC / PC with |sin(knee)| < 1e-4 on a leg: status 3 on the device exactly where the oracle reports it, torques and
-    metrics written (finite, non-zero); the single-robot mirror raises SolverError carrying status and torques; ID / CLF on the
+    metrics written (finite, non-zero); the single-robot mirror warns and returns the torques (strict=True: SolverError carrying status and torques); ID / CLF on the
     same states: status 0 and parity (include/wbc.h, mptc_controller.py:237-238)."""
     from oracle import oracle_py as orc
     from quadruped_drake_amd import IDController, MPTCController, PCController, CLFController, workloads, SolverError
@@ -308,6 +321,14 @@ def test_ill_conditioned_ticks_are_reported_not_hidden():
         d["p_" + f] = b["targets"][18 + 9 * i:21 + 9 * i, 0]; d["pd_" + f] = np.zeros(3); d["pdd_" + f] = np.zeros(3)
     d.update(rpy_body=np.zeros(3), p_body=b["targets"][0:3, 0], rpyd_body=np.zeros(3), pd_body=np.zeros(3),
              rpydd_body=np.zeros(3), pdd_body=np.zeros(3), contact_states=[True, False, False, True])
+    # the reference's assert passes in this state and it applies the torques: the mirror warns and returns them ...
+    from quadruped_drake_amd import IllConditionedWarning
+    with pytest.warns(IllConditionedWarning):
+        u = c.ControlLaw(q[:, 0], b["v"][:, 0], d)
+    assert c.last_status == 3 and np.isfinite(u).all() and np.abs(u).max() > 0
+    c.close()
+    # ... unless asked to be strict
+    c = MPTCController(max_batch=1, device=0, strict=True)
     with pytest.raises(SolverError) as ei:
         c.ControlLaw(q[:, 0], b["v"][:, 0], d)
     assert ei.value.args[1] == 3 and "ill-conditioned" in ei.value.args[0] and np.isfinite(ei.value.args[2]).all()
@@ -345,7 +366,7 @@ def test_full_size_properties(cfg, n):
     sl = lambda a: None if a is None else (a[:, idx] if a.ndim == 2 else a[idx])
     tau_o, _, _ = orc.step_batch("mptc", orc.model(b["model"]), orc.params("mptc"), sl(b["q"]), sl(b["v"]),
                                  sl(b["targets"]), sl(b["mask"]), sl(b["mu"]), sl(b["mass_scale"]))
-    assert rel_err(tau1[:, idx], tau_o).max() < TOL
+    assert rel_err(tau1[:, idx], tau_o).max() < TOL_TROT
     ctrl.close()
 
 
@@ -372,10 +393,64 @@ def test_full_size_oracle_parity(cfg, kind, n):
                                         b["mu"], b["mass_scale"], nthreads=cores)
     assert (st == 0).all() and (st_o == 0).all()
     r = rel_err(tau, tau_o)
-    assert r.max() < TOL, (r.max(), int(r.argmax()))
+    assert r.max() < tol_for(cfg), (r.max(), int(r.argmax()))
     assert np.median(r) < 1e-9
     assert np.allclose(met, met_o, rtol=1e-5, atol=1e-6)
     assert stats["ticks"] == n
+
+
+@pytest.mark.parametrize("kind", ["id", "mptc", "pc"])
+def test_saturated_stands_at_depth(kind):
+    """4-contact stands far outside their friction pyramids (BASELINE config 2's states under every law that has a stand): 10-27
+    active-set trips with drops, six internal-force directions carried at 1 / eps = 1e4 -- where the round-3 kernel was 1.6e-5
+    (ID) and 7e-5 ... 1.5e-4 (MPTC / PC) from the oracle with hundreds of instances above 1e-6 (profiles/r03/soak.md).  262 144 fresh
+    instances per law against the oracle on every usable host thread: the worst instance AND the population above 1e-6 are
+    asserted (round 3's default build fails both on every law; the reference solves these ticks like any other:
+    inverse_dynamics_controller.py:199-225, mptc_controller.py:285-296, pc_controller.py:229-237)."""
+    torch = _torch()
+    import bench
+    from oracle import oracle_py as orc
+    from quadruped_drake_amd import IDController, MPTCController, PCController, workloads
+    cls = {"id": IDController, "mptc": MPTCController, "pc": PCController}[kind]
+    cores = bench.cpu_limits()["usable"]
+    n, seeds = 16384, 16
+    ctrl = cls(model="mini_cheetah", max_batch=n, device=0)
+    worst, above6, above5, mism = 0.0, 0, 0, 0
+    for s in range(seeds):
+        b = workloads.make_batch(2, n=n, seed=50000 + 97 * s + 2)        # the seeds of tools/soak.py
+        up = lambda x: torch.tensor(x, device="cuda:0")
+        tau, met, st = ctrl.step(up(b["q"]), up(b["v"]), up(b["targets"]), up(b["mask"])); ctrl.sync()
+        tau, st = tau.cpu().numpy(), st.cpu().numpy()
+        tau_o, _, st_o = orc.step_batch(kind, orc.model(b["model"]), orc.params(kind), b["q"], b["v"], b["targets"], b["mask"], nthreads=cores)
+        mism += int((st != st_o).sum())
+        ok = (st == 0) & (st_o == 0)
+        r = rel_err(tau[:, ok], tau_o[:, ok])
+        worst = max(worst, float(r.max())); above6 += int((r > 1e-6).sum()); above5 += int((r > 1e-5).sum())
+    ctrl.close()
+    assert mism == 0
+    assert worst < TOL_STAND and above5 == 0, (worst, above6, above5)
+    assert above6 <= 8, (worst, above6)          # measured: 0 (ID, MPTC), 2 (PC: the double-precision oracle's own two outliers)
+
+
+@pytest.mark.parametrize("kind,cfg,n,bar", [("id", 2, 16384, 2e-6), ("mptc", 2, 16384, 2e-6), ("mptc", 3, 16384, 2e-7)])
+def test_against_the_extended_precision_oracle(kind, cfg, n, bar):
+    """The oracle's own source compiled with every double as x87 long double (oracle/ld, oracle/oracle_ld.py: test infrastructure)
+    is ~2000x closer to the unique solution of the strictly convex QP than either double-precision side, so it says whose
+    error a disagreement is.  The HIP path's OWN error is held to `bar`, and on the trot it has to be at least as close to the
+    extended reference as the double-precision oracle is (profiles/r04/truth.md)."""
+    import bench
+    from oracle import oracle_py as orc, oracle_ld as old
+    from quadruped_drake_amd import workloads
+    cores = bench.cpu_limits()["usable"]
+    b = workloads.make_batch(cfg, n=n, seed=424200 + cfg)
+    tau, met, st, _ = gpu_step(kind, b["model"], b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
+    tau_l, _, st_l = old.step_batch(kind, old.model(b["model"]), old.params(kind), b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"], nthreads=cores)
+    tau_o, _, st_o = orc.step_batch(kind, orc.model(b["model"]), orc.params(kind), b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"], nthreads=cores)
+    assert (st == 0).all() and (st_l == 0).all()
+    r = rel_err(tau, tau_l.astype(np.float64)); ro = rel_err(tau_o, tau_l.astype(np.float64))
+    assert r.max() < bar, (r.max(), ro.max())
+    if cfg != 2:
+        assert r.max() <= 2.0 * ro.max(), (r.max(), ro.max())
 
 
 def test_sub_batch_with_leading_dimension():
