@@ -364,15 +364,14 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   // (W R = I), so the reflection leaves every remaining image with a zero in slot q-1: the slot is free again, the list
   // stays a prefix, and there is no position bookkeeping and no per-position Givens sweep (round 2: up to 11 predicated
   // rotations with two 16-lane sums each; the divergent add / drop branches cost a lock-step trip both bodies).
-  double mk[NV];
-  if (generic) {
-#pragma unroll
-    for (int k = 0; k < NV; k++) mk[k] = (k >= q) ? 1.0 : 0.0;
-  }
-  bool dropped = false, wave_dropped = false;   // this (deep) robot has dropped a row / the wavefront has a deep robot and a drop (wave-uniform)
-  const bool wave_deep = generic && qo.wave_any(deep);
   WBC_GI_TIMERS;
-  for (int trip = 0; generic && trip < maxit; trip++) {
+  if (generic) {   // everything below -- the loop and the evaluation after a drop -- lives on this path only: nothing of it is live where the fast path's exit joins
+  double mk[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k++) mk[k] = (k >= q) ? 1.0 : 0.0;
+  bool dropped = false, wave_dropped = false;   // this (deep) robot has dropped a row / the wavefront has a deep robot and a drop (wave-uniform)
+  const bool wave_deep = qo.wave_any(deep);
+  for (int trip = 0; trip < maxit; trip++) {
     WBC_GI_T0();
     double d[NV], dm[NV], d2n = 0.0;
     double zd = 0.0, sd = 0.0, sdpc = 0.0, sdt = 0.0;
@@ -748,7 +747,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   // either way (measured on 130 of them).  Robots that never dropped keep the accumulated z; the code runs when any deep robot of
   // the wavefront has dropped, and a robot's result does not depend on its wave-mates.
 #ifndef WBC_NO_DROP_REFINE
-  if (generic && wave_dropped) {
+  if (wave_dropped) {
     // inhomogeneous rows (dense row: n.z = vc pc_inv;  torque row: (sig Tn).z = -bt - sig t0n) put g = sum beta_a W_a into the used slots
     double yk[NV], g[NV];
     const double b_pc = (PC && act_pc) ? vc * pc_inv : 0.0, b_t = (TB && act_t) ? -(bt + sig_t * t0n) : 0.0;
@@ -780,6 +779,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     z = dropped ? zr : z;
   }
 #endif
+  }   // generic
   *iters_out = iters;
   if (!done && status == ST_OK) status = ST_ITER;
   return status;
