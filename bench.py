@@ -40,14 +40,19 @@ PEAK_FP64_VALU_TFLOPS = 78.6                      # MI355X vector FP64 (spec); F
 PEAK_HBM_GBS = 8000.0
 
 
+# what the identity of a kernel build covers: an explicit list (a stray backup file under csrc/ does not change it)
+KERNEL_SOURCES = ["quadruped_drake_amd/csrc/hipcc_flags.txt", "quadruped_drake_amd/csrc/wbc_hex.hpp", "quadruped_drake_amd/csrc/wbc_kernels.hip",
+                  "quadruped_drake_amd/csrc/wbc_model.hpp", "quadruped_drake_amd/csrc/wbc_tick.hpp", "quadruped_drake_amd/csrc/wbc_traj.hip",
+                  "quadruped_drake_amd/csrc/wbc_traj_dev.hpp", "include/wbc.h", "include/wbc_extras.h"]
+
+
 def kernel_src_sha16():
-    """Identity of the kernel sources and their code-generation flags (everything under csrc/, hipcc_flags.txt included, + the
-    C ABI header): committed counter files carry it, and a counter file that was collected on another build is not mixed with
+    """Identity of the kernel sources and their code-generation flags (KERNEL_SOURCES: the files of csrc/, hipcc_flags.txt included, + the
+    C ABI headers): committed counter files carry it, and a counter file that was collected on another build is not mixed with
     this build's launch time (roofline.issued becomes null instead)."""
     h = hashlib.sha256()
-    d = os.path.join(ROOT, "quadruped_drake_amd", "csrc")
-    for f in sorted(os.listdir(d)) + [os.path.join(ROOT, "include", "wbc.h")]:
-        with open(f if os.path.isabs(f) else os.path.join(d, f), "rb") as fh:
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
 
@@ -435,13 +440,27 @@ def run_rank(a):
     sync(); barrier(); sync()
     dt = time.perf_counter() - t0
     per_rank_kernel_ms = [ms_per_launch]
+    # parity on EVERY rank: 64 instances spread over this rank's shard against the oracle (the checker), status of the whole shard
+    par_rel, par_bad = 0.0, float((out[2] != 0).sum())
+    if not a.no_cpu_baseline:
+        from oracle import oracle_py as orc
+        idx = np.unique(np.linspace(0, n - 1, min(64, n)).astype(int))
+        sl = lambda x: None if x is None else (x[:, idx] if x.ndim == 2 else x[idx])
+        tau_o, _, st_o = orc.step_batch(shard["kind"], orc.model(shard["model"]), orc.params(shard["kind"]), sl(shard["q"]), sl(shard["v"]),
+                                        sl(shard["targets"]), sl(shard["mask"]), sl(shard["mu"]), sl(shard["mass_scale"]))
+        tau_g = out[0][:, torch.tensor(idx, device=dev)].cpu().numpy()
+        par_rel = float((np.abs(tau_g - tau_o).max(0) / np.maximum(np.abs(tau_o).max(0), 1e-3)).max())
+        par_bad += float((st_o != 0).sum())
+    per_rank_rel, bad_total = [par_rel], par_bad
     if use_pg:
-        tt = torch.tensor([dt, ms_per_launch, dt_cold, ms_cold], dtype=torch.float64, device=cdev)
+        tt = torch.tensor([dt, ms_per_launch, dt_cold, ms_cold, par_rel, par_bad], dtype=torch.float64, device=cdev)
         parts = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(parts, tt)
         allr = torch.stack(parts).cpu().numpy()
         per_rank_kernel_ms = [float(x) for x in allr[:, 1]]
-        dt, ms_per_launch, dt_cold, ms_cold = (float(x) for x in allr.max(0))     # MAX over ranks
+        per_rank_rel = [float(x) for x in allr[:, 4]]
+        bad_total = float(allr[:, 5].sum())
+        dt, ms_per_launch, dt_cold, ms_cold = (float(x) for x in allr[:, :4].max(0))     # MAX over ranks
     # per-launch distribution (outside the timed region): one HIP event between every two launches
     each, _ = ctrl.time_steps_each(a.steps, q, v, tg, mask, mu, ms, out=out)
 
@@ -460,7 +479,7 @@ def run_rank(a):
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
                 tr = json.load(f)
             ent = tr.get("%s_cfg%d_n%d_%s" % (shard["kind"], cfg, n, used))
-            if ent:
+            if ent and ent.get("kernel_src_sha16") == kernel_src_sha16():     # counters of another kernel build are not mixed in
                 traffic = ent["bytes_per_launch"]
         except (OSError, ValueError):
             pass
@@ -469,7 +488,7 @@ def run_rank(a):
         issued = None
         try:
             if shard["kind"] == "mptc" and cfg == 3 and n == 4096:
-                with open(os.path.join(ROOT, "profiles", "r03", "hex_pmc.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r04", "hex_pmc.json")) as f:
                     pj = json.load(f)
                 if pj.get("kernel_src_sha16") != kernel_src_sha16():
                     raise KeyError("counter file is from another kernel build")
@@ -480,7 +499,7 @@ def run_rank(a):
                           "executed_frac_of_peak": ex / sec / 1e12 / PEAK_FP64_VALU_TFLOPS,
                           "redundancy": ex / (flops * n), "valu_insts_per_wavefront": g("SQ_INSTS_VALU") / g("SQ_WAVES"),
                           "mfma_insts": g("SQ_INSTS_MFMA"),
-                          "source": "profiles/r03/hex_pmc.json (rocprofv3 --pmc, separate passes of this command; same kernel "
+                          "source": "profiles/r04/hex_pmc.json (rocprofv3 --pmc, separate passes of this command; same kernel "
                                     "sources: sha16 %s)" % pj["kernel_src_sha16"]}
         except (OSError, ValueError, KeyError):
             pass
@@ -511,17 +530,25 @@ def run_rank(a):
                                          "the dense FP64 peak (78.6 TFLOP/s, the same figure for FP64 MFMA and FP64 VALU); the "
                                          "kernel issues v_fma_f64, not MFMA (profiles/r02/micro_mfma_f64.md)",
                          "note": "HBM does not bind this path (SURVEY 8d): 864 algorithmic bytes per 37.6 kflop tick; HBM fraction stated beside it"},
-            "status_nonzero": int((status != 0).sum()),
+            "status_nonzero": int(bad_total),                     # every rank's whole shard (+ its oracle sample), summed
+            "torque_rel_err_vs_cpu_ref": (max(per_rank_rel) if not a.no_cpu_baseline else None),
+            "per_rank_torque_rel_err": (per_rank_rel if not a.no_cpu_baseline else None),
+            "parity_sample": "64 instances spread over EVERY rank's shard against the oracle on that rank's host; maximum over ranks",
             "rollout_stats": {k: st[k] for k in ("ticks", "status_nonzero", "iters_sum", "tau_abs_max")},
             "iters_per_tick": st["iters_sum"] / max(1.0, st["ticks"]),
             "kernel_info": ctrl.kernel_info(),
         }
+        if world > 1 and not a.no_cpu_baseline:
+            # the N > 1 line carries the CPU baseline as well: rank 0's host cores on rank 0's shard (the other ranks wait at the
+            # closing barrier; outside the timed region)
+            line["cpu_baseline"] = cpu_baseline(shard, a.cpu_seconds)
         if world == 1 and not a.no_cpu_baseline:
             line["n32768"] = large_batch(local)                       # informational, outside the timed region
             line["closed_loop"] = closed_loop(shard, local)           # informational, outside the timed region
             line["config1_gpu"] = config1_gpu(local)                  # BASELINE configs[0] on the product path (informational)
             line["cpu_baseline"] = cpu_baseline(batch, a.cpu_seconds)
-            # parity beside the number: full torque vector (tier ii) and the solver-independent accelerations (tier i)
+            # parity beside the number: full torque vector (tier ii, 256 leading instances on top of the per-rank sample) and the
+            # solver-independent accelerations (tier i)
             from oracle import oracle_py as orc
             k = 256
             tau_gpu = out[0][:, :k].cpu().numpy()
@@ -530,7 +557,7 @@ def run_rank(a):
                                          sl(batch["q"]), sl(batch["v"]), sl(batch["targets"]), sl(batch["mask"]),
                                          sl(batch["mu"]), sl(batch["mass_scale"]))
             rel = np.abs(tau_gpu - tau_o).max(0) / np.maximum(np.abs(tau_o).max(0), 1e-3)
-            line["torque_rel_err_vs_cpu_ref"] = float(rel.max())
+            line["torque_rel_err_vs_cpu_ref"] = max(line["torque_rel_err_vs_cpu_ref"], float(rel.max()))
             vd = torch.zeros((18, n), dtype=torch.float64, device=dev)
             ctrl.set_vdot_output(vd)
             ctrl.step(q, v, tg, mask, mu, ms, out=out); ctrl.sync()

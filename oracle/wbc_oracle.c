@@ -17,6 +17,13 @@
 #endif
 
 /* ------------------------------------------------------------------ small dense helpers */
+/* Which status the task-space laws report on (nearly) straight knees: 1 (default) = the product's reporting convention of
+ * include/wbc.h mirrored (status 2 on an exactly singular foot Jacobian, status 3 on |sin(knee)| < 1e-4), so that checker and
+ * checked can be compared tick by tick; 0 = what the dense restatement itself returns there (its own solver's status, nothing
+ * mirrored) -- the independent view, tests/test_oracle_qp.py::test_raw_status_is_the_dense_solver_s_own. */
+static int g_product_status = 1;
+void orc_set_status_convention(int product) { g_product_status = product ? 1 : 0; }
+
 static void cross3(const double* a, const double* b, double* c) {
   double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   c[0] = x; c[1] = y; c[2] = z;
@@ -832,10 +839,11 @@ static int mptc_like_control_law(const orc_model* m, const orc_params* p, const 
   mm(mt, 18, 18, J, Minv, JMi);          /* J Minv */
   mmt(mt, 18, mt, JMi, J, Lam);          /* J Minv J' */
   bad |= mat_inv(mt, Lam);               /* Lambda */
-  /* the product's status convention (include/wbc.h), mirrored: a leg whose 3x3 foot Jacobian block is singular to rounding
+  /* (only under orc_set_status_convention(1), the default; 0 = the dense restatement's own status, nothing mirrored)
+   * the product's status convention (include/wbc.h), mirrored: a leg whose 3x3 foot Jacobian block is singular to rounding
    * (|det| <= 1e-12: an exactly straight knee) makes J Minv J' singular up to rounding noise -- mat_inv above may or may not
    * notice -- and is reported as status 2 with zero torques, not solved */
-  for (int l = 0; l < 4; l++) {
+  for (int l = 0; l < 4 && g_product_status; l++) {
     const double* B = T->J_feet[l] + 6 + 3 * l;   /* rows 18 apart */
     double det = B[0] * (B[19] * B[38] - B[20] * B[37]) - B[1] * (B[18] * B[38] - B[20] * B[36]) + B[2] * (B[18] * B[37] - B[19] * B[36]);
     if (!(fabs(det) > 1e-12)) bad = 1;
@@ -930,7 +938,7 @@ static int mptc_like_control_law(const orc_model* m, const orc_params* p, const 
   if (bad) { for (int k = 0; k < 12; k++) tau[k] = 0; qp->status = 2; }
   /* the product's status convention (include/wbc.h), mirrored so that the checker and the checked agree on it: a solved tick
    * with a nearly straight knee (|sin| < 1e-4: inv(J Minv J') above has lost its digits) is reported as 3 */
-  if (status == 0)
+  if (status == 0 && g_product_status)
     for (int l = 0; l < 4; l++)
       if (fabs(sin(q[7 + 3 * l + 2])) < 1e-4) status = 3;
   if (status == 3) qp->status = 3;

@@ -64,6 +64,7 @@ typedef struct {
   double tiebreak_eps2; /* weight of the 1/2*eps2*|[tau;f]|^2 tie-break; see DESIGN.md */
 } orc_params;
 
+void orc_set_status_convention(int product);   /* 1 (default): include/wbc.h's status 2 / 3 on straight knees mirrored; 0: the dense solver's own */
 void orc_model_from_flat(const double* flat215, orc_model* m);
 void orc_params_id_default(orc_params* p);   /* inverse_dynamics_controller.py:117-127 */
 void orc_params_mptc_default(orc_params* p); /* mptc_controller.py:143-153 */

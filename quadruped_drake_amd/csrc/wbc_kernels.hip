@@ -62,13 +62,66 @@ static_assert(sizeof(StatsDev) == 22 * 8, "StatsDev is 22 eight-byte words (wbc_
 // slots as one coalesced stream (the slot-major layout cost 11 us per wbc_stats_get, profiles/r02/hex_kernel_stats.csv).
 __device__ __forceinline__ void stat_add(StatsDev* stats, unsigned block, int st, int iters, double tau_sum, double tau_max, double err, unsigned mk) {
   double* w = reinterpret_cast<double*>(stats) + (block & (STAT_SLOTS - 1));
-  atomicAdd(w + 0 * STAT_SLOTS, 1.0);
-  if (st != 0) atomicAdd(w + 1 * STAT_SLOTS, 1.0);
+  if (st != 0) atomicAdd(w + 1 * STAT_SLOTS, 1.0);      // (word 0, `ticks`, is not accumulated: it is the sum of the 16 mask bins, wbc_stats_get)
   atomicAdd(w + 2 * STAT_SLOTS, (double)iters);
   atomicAdd(w + 3 * STAT_SLOTS, tau_sum);
   atomicMax(reinterpret_cast<unsigned long long*>(w + 4 * STAT_SLOTS), (unsigned long long)__double_as_longlong(tau_max));
   atomicAdd(w + 5 * STAT_SLOTS, err);
   atomicAdd(w + (6 + mk) * STAT_SLOTS, 1.0);
+}
+// The tick kernels (the launches whose HBM traffic is reported) do it per wavefront, not per robot (round 4; rounds 1-3 and the
+// persistent rollout kernels, which have no register to spare: the helper above, 7 atomics from each robot's lead lane): the four robots' contributions (each replicated on its robot's 16-lane
+// row) are folded with the two wavefront-broadcast DPP steps (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3:
+// lane 63 holds the total) and ONE lane issues the atomics: 6 lane-atomics per wavefront instead of 28.  Every atomic costs a
+// 32-byte write in HBM (WRITE_SIZE 1296 B per wavefront against 528 B of outputs); what time it takes does not matter
+// (HBM is at 2 % of its peak), the byte count is reported in roofline.traffic.
+__device__ __forceinline__ double wave4_sum(double x) {
+  x += __builtin_amdgcn_update_dpp(0.0, x, 0x142, 0xA, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0.0, x, 0x143, 0xC, 0xF, false);
+  return x;
+}
+__device__ __forceinline__ double wave4_max(double x) {   // x >= 0, never NaN (compare + select: fmax() of a DPP result breaks this compiler's -save-temps bitcode round trip)
+  const double a = __builtin_amdgcn_update_dpp(0.0, x, 0x142, 0xA, 0xF, false);
+  x = (a > x) ? a : x;
+  const double b = __builtin_amdgcn_update_dpp(0.0, x, 0x143, 0xC, 0xF, false);
+  return (b > x) ? b : x;
+}
+__device__ __forceinline__ int wave4_sum(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  return x;
+}
+__device__ __forceinline__ void stat_add_wave(StatsDev* stats, unsigned block, bool live, int st, int iters, double tau_sum, double tau_max,
+                                              double err, unsigned mk) {
+  const int n = wave4_sum(live ? 1 : 0), bad = wave4_sum((live && st != 0) ? 1 : 0), it = wave4_sum(live ? iters : 0);
+  const double ts = wave4_sum(live ? tau_sum : 0.0), tm = wave4_max(live ? tau_max : 0.0), er = wave4_sum(live ? err : 0.0);
+  (void)n;   // `ticks` is not accumulated: every live robot lands in exactly one mask bin, wbc_stats_get adds the 16 bins up
+  double* w = reinterpret_cast<double*>(stats) + (block & (STAT_SLOTS - 1));
+  if ((threadIdx.x & 63) == 63) {
+    if (bad) atomicAdd(w + 1 * STAT_SLOTS, (double)bad);
+    atomicAdd(w + 2 * STAT_SLOTS, (double)it);
+    atomicAdd(w + 3 * STAT_SLOTS, ts);
+    atomicMax(reinterpret_cast<unsigned long long*>(w + 4 * STAT_SLOTS), (unsigned long long)__double_as_longlong(tm));
+    atomicAdd(w + 5 * STAT_SLOTS, er);
+  }
+#ifdef WBC_STATS_DISTINCT_MASKS
+  // contact masks: one atomic per DISTINCT mask of the wavefront (a stand: one, a trot: two), from the first robot that carries it
+  const unsigned row = (threadIdx.x >> 4) & 3u;
+  int cnt = 0;
+  bool first = true;
+#pragma unroll
+  for (unsigned j = 0; j < 4; j++) {
+    const unsigned mj = __builtin_amdgcn_readlane(mk, 16 * j);
+    const bool lj = __builtin_amdgcn_readlane(live ? 1 : 0, 16 * j) != 0;
+    const bool eq = lj && mj == mk;
+    cnt += eq ? 1 : 0;
+    first = first && !(eq && j < row);
+  }
+  if (live && first && (threadIdx.x & 15) == 0) atomicAdd(w + (6 + mk) * STAT_SLOTS, (double)cnt);
+#else
+  // contact masks: one lane-atomic per robot (one instruction for the four lead lanes)
+  if (live && (threadIdx.x & 15) == 0) atomicAdd(w + (6 + mk) * STAT_SLOTS, 1.0);
+#endif
 }
 
 __device__ __forceinline__ double wave_sum(double x) {
@@ -383,12 +436,10 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* __restric
   WBC_STAMP(4);   // tick done
   if (live && lead && status) status[ii] = st;
   if (stats) {
-    // per-robot reductions on the DPP row, then fire-and-forget atomics from the robot's lead lane into
-    // the block's slot (no wave-wide shuffles, no waits at the tail of the kernel)
+    // per-robot reductions on the DPP row, the four robots folded on the wavefront, then fire-and-forget atomics from ONE lane
+    // into the block's slot (no waits at the tail of the kernel)
     const double ts = qo.sum16(tsum), tm = qo.max16(tmax);
-    if (live && lead) {
-      stat_add(stats, blockIdx.x, st, iters, ts, tm, errv, mk);
-    }
+    stat_add_wave(stats, blockIdx.x, live, st, iters, ts, tm, errv, mk);
   }
   WBC_STAMP(5);
 }
@@ -931,7 +982,9 @@ int wbc_stats_get(wbc_handle h, wbc_stats* out) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));   // the only wait: the totals are already in host memory
   memcpy(&s, h->h_stats, sizeof s);
-  out->ticks = s.ticks; out->status_nonzero = s.status_nonzero; out->iters_sum = s.iters_sum;
+  out->ticks = 0.0;   // every stepped instance landed in exactly one contact-mask bin: no atomic is spent on the total
+  for (int k = 0; k < 16; k++) out->ticks += s.mask_count[k];
+  out->status_nonzero = s.status_nonzero; out->iters_sum = s.iters_sum;
   out->tau_abs_sum = s.tau_abs_sum; out->err_sum = s.err_sum;
   double mx; memcpy(&mx, &s.tau_abs_max_bits, 8);
   out->tau_abs_max = mx;

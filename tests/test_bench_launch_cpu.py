@@ -57,13 +57,17 @@ import pytest
 def test_self_launch_two_ranks_compute_on_the_gpu():
     """The self-launched N > 1 path with the REAL kernel: two rank processes, contiguous shards of BASELINE config 5's batch,
     one statistics all-gather -- both ranks share GPU 0 here (gloo test switch; RCCL needs one device per rank)."""
-    r = _run(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "5", "--warmup", "2", "--ramp-seconds", "0", "--per-gpu", "512"],
-             timeout=600)
+    r = _run(["--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "5", "--warmup", "2", "--ramp-seconds", "0", "--per-gpu", "512",
+              "--cpu-seconds", "0.5"], timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert "dry_run" not in d and d["n_gpus"] == 2 and d["ranks_seen"] == 2
     assert d["per_rank_ticks"] == [512.0 * 5, 512.0 * 5] and d["rollout_stats"]["ticks"] == 2 * 512 * 5
     assert d["status_nonzero"] == 0 and d["value"] > 0 and d["config"]["domain_randomised"] is True
+    # the N > 1 line carries its own parity and CPU baseline: every rank checked 64 instances of ITS shard against the oracle
+    assert len(d["per_rank_torque_rel_err"]) == 2 and all(0.0 < e < 1e-6 for e in d["per_rank_torque_rel_err"])
+    assert d["torque_rel_err_vs_cpu_ref"] == max(d["per_rank_torque_rel_err"])
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
 
 
 @pytest.mark.gpu
@@ -105,4 +109,9 @@ def test_bench_one_gpu_through_the_process_group_branch():
     assert d["process_group"] == "nccl" and d["n_gpus"] == 1 and d["ranks_seen"] == 1
     assert d["per_rank_ticks"] == [4096.0 * 10] and len(d["per_rank_kernel_ms"]) == 1 and d["per_rank_kernel_ms"][0] > 0
     assert d["status_nonzero"] == 0 and d["value"] > 0 and d["value_cold"] > 0
-    assert d["roofline"]["traffic"] is not None
+    # HBM bytes per launch are replayed from the committed counter file -- only when it was collected on THIS kernel build
+    import bench
+    with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+        ent = json.load(f)["mptc_cfg3_n4096_hex"]
+    same_build = ent.get("kernel_src_sha16") == bench.kernel_src_sha16()
+    assert (d["roofline"]["traffic"] == ent["bytes_per_launch"]) if same_build else (d["roofline"]["traffic"] is None)
