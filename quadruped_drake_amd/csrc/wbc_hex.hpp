@@ -22,17 +22,6 @@
 #include <type_traits>
 #include <utility>
 #include "wbc_tick.hpp"
-// WBC_GIVENS_DROPS = 1: the task-space laws (MPTC, PC) drop an active row by Givens rotations computed from the images (round 2's
-// arithmetic inside round 3's straight-line trip) instead of the one Householder reflection of its W row.  Measured on 524 288 random
-// 4-contact STANDS per law (not a BASELINE configuration; tools/soak.py cases 8, 9; profiles/r03/soak.md), instances whose torques
-// differ from the oracle's by more than 1e-6 / 1e-5 / 1e-4:  MPTC  W-row reflection 604 / 36 / 1, Givens 121 / 3 / 1 (round-2 kernel
-// 110 / 4 / 0);  PC  392 / 39 / 0, 137 / 9 / 0 (143 / 10 / 1).  The price: MPTC trot N = 4096 26.3 -> 28.0 us (the launch ends with the
-// few wavefronts that drop), PC 31.4 -> 36.9 us, N = 32768 +2.5 %.  On every BASELINE configuration both agree with the oracle to
-// 2e-7 (trots) / 2e-5 (ID stand), so the default is the cheaper reflection; builds that tick task-space laws on saturated stands can
-// switch.
-#ifndef WBC_GIVENS_DROPS
-#define WBC_GIVENS_DROPS 0
-#endif
 // WBC_QRF bit 0: hardware-seeded sqrt in the Householder steps; bit 1: the same for the reciprocal (round 1: bit 1
 // made the MPTC kernel spill; with the single 30-row append of round 2 it does not and saves ~140 instructions)
 #ifndef WBC_QRF
@@ -172,8 +161,7 @@ WBC_HD int hex_key_index(double k) {
 //   * J' N_A = [R; 0]: column c of the triangular factor IS Dh[0..c] of the row at position c, so R is never
 //     stored; the lane of the active row at position c (pos_h == c) carries row c of W = R^-1 instead, so the dual
 //     direction r = W d[0:q] is one lane-local dot product (no back-substitution chain).  Appending a
-//     row appends the column [-r/alpha; 1/alpha] to W; dropping one applies the re-triangularising
-//     Givens rotations to the slots of (Jr, Dh, Wr) alike and renumbers the positions;
+//     row appends the column [-r/alpha; 1/alpha] to W; dropping one reflects its W row onto the last used slot (below);
 //   * the blocking multiplier is a lane-parallel ratio + argmin.
 // Nothing lives in LDS and the loop has no divergent inner branches (profiles/r02/hex_cuts.md).
 // The optional dense row (index 16: the PC law's Vdot <= 0, the CLF law's CLF row) has its image / value /
@@ -182,7 +170,7 @@ WBC_HD int hex_key_index(double k) {
 // joint in a second constraint slot (id 32 + lane): unit normal Tn of the torque-map row, normalised torque
 // yt = Tn.z + t0n tracked like s_h, bound bt = tau_max / |T_row| (< 0: slot not eligible).  Only one side of a
 // pair can be violated or active at a time; the side is a sign (sig) applied to the slot's image.
-template <class Q, bool PC, int NV = NZ, bool TB = false, bool GAIN = false, bool GIV = false>
+template <class Q, bool PC, int NV = NZ, bool TB = false, bool GAIN = false>
 WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, double inv_s, int* iters_out,
                   double vrow_own = 0.0, double vc = 0.0, double pc_inv = 0.0, const double* Tn = nullptr,
                   double t0n = 0.0, double bt = -1.0, bool deep = true) {
@@ -207,7 +195,6 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   }
   double u_h = 0.0, Wr[NV], Wpc[NV];
   bool act_h = false;   // own friction row is in the active set
-  int pos_h = -1, pos_pc = -1, pos_t = -1;   // GIV: list positions of the own friction row / the dense row / the own torque row
 #pragma unroll
   for (int k = 0; k < NV; k++) { Wr[k] = 0.0; Wpc[k] = 0.0; }
   double Dt[NV], Wt[NV], yt = 0.0, dnt = 0.0, u_t = 0.0, sig_t = 1.0;
@@ -350,7 +337,6 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         Wr[qc] = mine ? ia : -r_h * ia;
         u_h = mine ? t2 : u_h;
         act_h = act_h || mine;
-        if (GIV) pos_h = mine ? qc : pos_h;
         q = qc + 1;
       }
     });
@@ -523,91 +509,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     const bool anyd = qo.wave_any(drop);
     dropped = dropped || (drop && deep);
     wave_dropped = wave_dropped || (anyd && wave_deep);
-    if (GIV && anyd) {
-      // Drop by Givens rotations computed from the IMAGES (the task-space laws: their stands are where the accuracy of the
-      // cheaper W-row reflection below shows, profiles/r03/soak.md): the images stay triangular in list order; removing the
-      // column at position ld leaves one sub-diagonal entry in each later column, rotated away in slot pairs (j, j+1).  The
-      // chain is entered at the wavefront's first position and left at its last: two taken branches, no per-position skips.
-      WBC_GI_STAT(if (h == 0 && drop) g_gi_drops++);
-      int ld = qo.bcast16d_i((TB && hd >= 32) ? pos_t : pos_h, hd & 15);
-      if (PC) ld = (hd == 16) ? pos_pc : ld;
-      ld = drop ? ld : NV;
-      const int qn = drop ? q - 1 : q;
-      {
-        const bool mined = drop && (h == hd);
-        const double keep = mined ? 0.0 : 1.0;
-        u_h = mined ? 0.0 : u_h;
-        act_h = act_h && !mined;
-        pos_h = mined ? -1 : ((pos_h > ld) ? pos_h - 1 : pos_h);
-#pragma unroll
-        for (int k = 0; k < NV; k++) Wr[k] *= keep;
-      }
-      if (TB) {
-        const bool tmd = drop && (hd == 32 + h);
-        const double keep = tmd ? 0.0 : 1.0;
-        u_t = tmd ? 0.0 : u_t; act_t = act_t && !tmd;
-        pos_t = tmd ? -1 : ((pos_t > ld) ? pos_t - 1 : pos_t);
-#pragma unroll
-        for (int k = 0; k < NV; k++) Wt[k] *= keep;
-      }
-      if (PC) {
-        const bool pmd = drop && (hd == 16);
-        const double keep = pmd ? 0.0 : 1.0;
-        u_pc = pmd ? 0.0 : u_pc; act_pc = act_pc && !pmd;
-        pos_pc = pmd ? -1 : ((pos_pc > ld) ? pos_pc - 1 : pos_pc);
-#pragma unroll
-        for (int k = 0; k < NV; k++) Wpc[k] *= keep;
-      }
-      const int jlo = NV - qo.wave_max_int(drop ? NV - ld : 0), jhi = qo.wave_max_int(drop ? qn : 0);   // wave-uniform
-      auto rot = [&](auto JJ) {
-        constexpr int j = JJ;
-        const bool on = (j >= ld) && (j < qn);
-        // (a, b) = entries (j, j+1) of the column now at position j: the image of the row whose position is j
-        const bool here = (pos_h == j), here_t = TB && (pos_t == j);
-        double a = qo.sum16(here ? Dh[j] : (here_t ? sig_t * Dt[j] : 0.0)),
-               b = qo.sum16(here ? Dh[j + 1] : (here_t ? sig_t * Dt[j + 1] : 0.0));
-        if (PC) { a = (pos_pc == j) ? Dpc[j] : a; b = (pos_pc == j) ? Dpc[j + 1] : b; }
-        const double ih = fast_rcp(fast_sqrt(a * a + b * b));
-        const double c = on ? a * ih : 1.0, sn = on ? b * ih : 0.0;   // a robot this position does not concern: identity
-        { const double x = Wr[j], y = Wr[j + 1]; Wr[j] = c * x + sn * y; Wr[j + 1] = c * y - sn * x; }
-        { const double x = Jr[j], y = Jr[j + 1]; Jr[j] = c * x + sn * y; Jr[j + 1] = c * y - sn * x; }
-        { const double x = Dh[j], y = Dh[j + 1]; Dh[j] = c * x + sn * y; Dh[j + 1] = c * y - sn * x; }
-        if (PC) {
-          { const double x = Wpc[j], y = Wpc[j + 1]; Wpc[j] = c * x + sn * y; Wpc[j + 1] = c * y - sn * x; }
-          { const double x = Dpc[j], y = Dpc[j + 1]; Dpc[j] = c * x + sn * y; Dpc[j + 1] = c * y - sn * x; }
-        }
-        if (TB) {
-          { const double x = Wt[j], y = Wt[j + 1]; Wt[j] = c * x + sn * y; Wt[j + 1] = c * y - sn * x; }
-          { const double x = Dt[j], y = Dt[j + 1]; Dt[j] = c * x + sn * y; Dt[j + 1] = c * y - sn * x; }
-        }
-      };
-#define WBC_ROT_CASE(J)                                                                  \
-        case J:                                                                          \
-          if constexpr (J < NV - 1) {                                                    \
-            if (J >= jhi) break;                                                         \
-            rot(std::integral_constant<int, (J < NV - 1) ? J : 0>{});                    \
-          }                                                                              \
-          [[fallthrough]];
-      switch (jlo) {
-        WBC_ROT_CASE(0) WBC_ROT_CASE(1) WBC_ROT_CASE(2) WBC_ROT_CASE(3) WBC_ROT_CASE(4) WBC_ROT_CASE(5)
-        WBC_ROT_CASE(6) WBC_ROT_CASE(7) WBC_ROT_CASE(8) WBC_ROT_CASE(9) WBC_ROT_CASE(10) WBC_ROT_CASE(11)
-        default: break;
-      }
-#undef WBC_ROT_CASE
-      q = qn;
-      // q - 1 for the dropping robots: mk gains the one-hot of slot q - 1; the vacated slot of every W row is zero again
-      const double dl = drop ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < NV; k++) mk[k] = fmad(dl, ((k + 1 < NV) ? mk[k + 1] : 1.0) - mk[k], mk[k]);
-#pragma unroll
-      for (int k = 0; k < NV; k++) {
-        const double e = dl * ((k > 0) ? mk[k] - mk[k - 1] : mk[0]);
-        Wr[k] = fmad(-e, Wr[k], Wr[k]);
-        if (PC) Wpc[k] = fmad(-e, Wpc[k], Wpc[k]);
-        if (TB) Wt[k] = fmad(-e, Wt[k], Wt[k]);
-      }
-    }
-    if (!GIV && anyd) {
+    if (anyd) {
       WBC_GI_STAT(if (h == 0 && drop) g_gi_drops++);
       double w[NV];
 #pragma unroll
@@ -652,7 +554,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     xq += xq1;
     const double alpha = (xq > 0.0) ? -nrm : nrm;
     const double ia = (xq > 0.0) ? -rsn : rsn;
-    const double beta = (full || (!GIV && drop)) ? fast_rcp(nrm * (nrm + fabs(xq))) : 0.0;   // 2 / (v'v); null reflection for a robot that rests
+    const double beta = (full || drop) ? fast_rcp(nrm * (nrm + fabs(xq))) : 0.0;   // 2 / (v'v); null reflection for a robot that rests
     // y . v = y . x - alpha y_q (the dots with x are there already; y_q picked by the one-hot mask)
     double jq = 0.0, dhq = 0.0, dpq = 0.0, dtq = 0.0;
     double hv[NV];
@@ -673,7 +575,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       if (PC) Dpc[k] = fmad(-wp, hv[k], Dpc[k]);
       if (TB) Dt[k] = fmad(-wt, hv[k], Dt[k]);
     }
-    if (!GIV && anyd) {
+    if (anyd) {
       // W' = W H on the rows; the freed slot is zero again in every W row (appends add into it: an appending robot's slot q
       // is still zero here, so clearing it is harmless), the dropped row's own W row is cleared
       double wrq = 0.0, wpq = 0.0, wtq = 0.0;
@@ -708,14 +610,12 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       for (int k = 0; k < NV; k++) Wr[k] = fmad(eq[k], wq, Wr[k]);
       u_h = mine ? up : u_h;
       act_h = act_h || mine;
-      if (GIV) pos_h = mine ? q : pos_h;
       if (TB) {
         const bool tm = full && (p == 32 + h);
         const double wqt = full ? (tm ? ia : -r_t * ia) : 0.0;
 #pragma unroll
         for (int k = 0; k < NV; k++) Wt[k] = fmad(eq[k], wqt, Wt[k]);
         u_t = tm ? up : u_t; act_t = act_t || tm; sig_t = tm ? sgp : sig_t;
-        if (GIV) pos_t = tm ? q : pos_t;
       }
       if (PC) {
         const bool pm = full && (p == 16);
@@ -723,7 +623,6 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
         for (int k = 0; k < NV; k++) Wpc[k] = fmad(eq[k], wqp, Wpc[k]);
         u_pc = pm ? up : u_pc; act_pc = act_pc || pm;
-        if (GIV) pos_pc = pm ? q : pos_pc;
       }
       const double fl = full ? 1.0 : 0.0;
       if (full) { q++; need_pick = true; }
@@ -1544,7 +1443,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     (void)s;
     int st;
     if (KIND == KIND_PC) {
-      st = hex_gi<Q, true, NV, TB, false, WBC_GIVENS_DROPS != 0>(qo, h, ct, Jr, z, mu * rs, rs, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt, deep);
+      st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu * rs, rs, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt, deep);
     } else if (KIND == KIND_CLF) {
       // the CLF row  g . [z; delta] - ub <= 0  is the dense row of the active set (index 16), like PC's Vdot row
       st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu * rs, rs, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt, deep);
@@ -1552,7 +1451,7 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
 #ifndef WBC_GAIN_ID
 #define WBC_GAIN_ID 0
 #endif
-      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC || (WBC_GAIN_ID && KIND == KIND_ID)) && !TB, (WBC_GIVENS_DROPS != 0) && KIND == KIND_MPTC>(qo, h, ct, Jr, z, mu * rs, rs, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt, deep);
+      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC || (WBC_GAIN_ID && KIND == KIND_ID)) && !TB>(qo, h, ct, Jr, z, mu * rs, rs, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt, deep);
     }
     if (st != ST_OK) status = st;
     if (status == ST_OK && illc) status = ST_ILLCOND;
