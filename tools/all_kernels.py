@@ -99,7 +99,7 @@ def run(name, outdir):
 
 def report(outdir):
     import csv
-    print("# Round 3: every product kernel under `rocprofv3 --kernel-trace --stats` (MI355X, one profiler run per workload, "
+    print("# Round %d: every product kernel under `rocprofv3 --kernel-trace --stats` (MI355X, one profiler run per workload, "
           "`tools/profile_round.sh`)\n")
     print("Average duration = the profiler's `AverageNs` over the run's launches (1 s of clock-ramp launches + 300 timed ones); fraction = "
           "counted flops per tick x instances / average duration / 78.6 TFLOP/s (FP64 vector peak).  The HIP-event column is the last 300 "
