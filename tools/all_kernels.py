@@ -99,8 +99,9 @@ def run(name, outdir):
 
 def report(outdir):
     import csv
-    print("# Round %d: every product kernel under `rocprofv3 --kernel-trace --stats` (MI355X, one profiler run per workload, "
-          "`tools/profile_round.sh`)\n")
+    rnd = "".join(c for c in os.path.basename(os.path.dirname(os.path.abspath(outdir))) if c.isdigit()) or "?"   # gpurun_out/r04/all -> 4
+    print("# Round %s: every product kernel under `rocprofv3 --kernel-trace --stats` (MI355X, one profiler run per workload, "
+          "`tools/profile_round.sh`)\n" % rnd.lstrip("0"))
     print("Average duration = the profiler's `AverageNs` over the run's launches (1 s of clock-ramp launches + 300 timed ones); fraction = "
           "counted flops per tick x instances / average duration / 78.6 TFLOP/s (FP64 vector peak).  The HIP-event column is the last 300 "
           "launches timed by `wbc_time_steps` inside the same PROFILED process: launch-to-launch time, i.e. the kernel plus the gap the "
