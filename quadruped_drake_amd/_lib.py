@@ -62,6 +62,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise WbcError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)" % LIB_PATH)
+        # ONE HIP runtime per process: libwbc_hip.so is linked against libamdhip64.so by soname and PyTorch-ROCm ships its own copy.
+        # Loaded after torch, the library binds to the copy torch already mapped; loaded BEFORE it (build() then smoke() in one
+        # process) the system copy comes in first, torch then maps its own, and the second runtime finds no device.  Device memory
+        # and streams are torch's here anyway, so torch goes first whenever it is installed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         l.wbc_last_error.restype = C.c_char_p
         l.wbc_version.restype = C.c_int
