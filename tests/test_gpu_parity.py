@@ -99,6 +99,36 @@ def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n):
     assert stats["mask_count"] == [float((b["mask"] == k).sum()) for k in range(16)]
 
 
+def test_stats_pack_is_stats_get_and_folds_like_the_collective():
+    """wbc_stats_pack = wbc_stats_get as the flat WBC_NSTAT vector a C caller hands to its own ncclAllGather; wbc_stats_reduce
+    folds gathered vectors (two handles = two ranks' shards here) into the statistics of the whole batch: ticks from the mask
+    bins, sums, the maximum of tau_abs_max -- equal to one handle stepping everything."""
+    torch = _torch()
+    import ctypes as C
+    from quadruped_drake_amd import MPTCController, _lib, workloads
+    b = workloads.make_batch(5, n=512)
+    up = lambda x: torch.tensor(np.ascontiguousarray(x), device="cuda:0")
+    L = _lib.lib()
+    vecs = []
+    for lo, hi in ((0, 200), (200, 512)):                       # two uneven shards (ragged last wavefront in the first)
+        c = MPTCController(model=b["model"], max_batch=512, device=0)
+        c.step(up(b["q"][:, lo:hi]), up(b["v"][:, lo:hi]), up(b["targets"][:, lo:hi]), up(b["mask"][lo:hi]), up(b["mu"][lo:hi]), up(b["mass_scale"][lo:hi]))
+        v = np.zeros(22)
+        _lib.check(L.wbc_stats_pack(c._h, v.ctypes.data_as(_lib.c_double_p)))
+        d = c.stats()
+        assert v[0] == d["ticks"] == hi - lo and v[4] == d["tau_abs_max"] and list(v[6:]) == d["mask_count"] and v[2] == d["iters_sum"]
+        vecs.append(v); c.close()
+    whole = MPTCController(model=b["model"], max_batch=512, device=0)
+    tau, _, _ = whole.step(up(b["q"]), up(b["v"]), up(b["targets"]), up(b["mask"]), up(b["mu"]), up(b["mass_scale"]))
+    ref = whole.stats(); whole.close()
+    g = np.ascontiguousarray(np.stack(vecs))
+    out = _lib.WbcStats()
+    _lib.check(L.wbc_stats_reduce(g.ctypes.data_as(_lib.c_double_p), 2, C.byref(out)))
+    assert out.ticks == 512.0 == ref["ticks"] and out.tau_abs_max == ref["tau_abs_max"] == float(tau.abs().max())
+    assert out.iters_sum == ref["iters_sum"] and list(out.mask_count) == ref["mask_count"]
+    assert abs(out.tau_abs_sum - ref["tau_abs_sum"]) < 1e-9 * ref["tau_abs_sum"]
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 5, 15, 16, 17, 63, 64, 65, 200])
 def test_ragged_batch_sizes(n):
     from oracle import oracle_py as orc
