@@ -38,6 +38,7 @@ FLOPS_PER_TICK = {("mptc", 3): 37629.0, ("mptc", 5): 37703.0, ("id", 2): 35667.0
 BYTES_PER_TICK = {False: 864.0, True: 880.0}     # SURVEY.md section 8(d); True = with mu and mass scale
 PEAK_FP64_VALU_TFLOPS = 78.6                      # MI355X vector FP64 (spec); FP64 MFMA peak is the same figure
 PEAK_HBM_GBS = 8000.0
+PMC_ROUND = "r05"                                  # profiles/<round>/hex_pmc.json: the committed counter pass roofline.issued restates
 
 
 # what the identity of a kernel build covers: an explicit list (a stray backup file under csrc/ does not change it)
@@ -441,7 +442,8 @@ def run_rank(a):
     dt = time.perf_counter() - t0
     per_rank_kernel_ms = [ms_per_launch]
     # parity on EVERY rank: 64 instances spread over this rank's shard against the oracle (the checker), status of the whole shard
-    par_rel, par_bad = 0.0, float((out[2] != 0).sum())
+    par_rel, par_bad = 0.0, float((out[2] != 0).sum())        # par_bad: the DEVICE's count over the whole shard, nothing else
+    par_obad, par_mis = 0.0, 0.0                                # oracle's non-zero statuses on the sample / sample instances whose status differs
     if not a.no_cpu_baseline:
         from oracle import oracle_py as orc
         idx = np.unique(np.linspace(0, n - 1, min(64, n)).astype(int))
@@ -450,16 +452,18 @@ def run_rank(a):
                                         sl(shard["targets"]), sl(shard["mask"]), sl(shard["mu"]), sl(shard["mass_scale"]))
         tau_g = out[0][:, torch.tensor(idx, device=dev)].cpu().numpy()
         par_rel = float((np.abs(tau_g - tau_o).max(0) / np.maximum(np.abs(tau_o).max(0), 1e-3)).max())
-        par_bad += float((st_o != 0).sum())
-    per_rank_rel, bad_total = [par_rel], par_bad
+        st_g = out[2][torch.tensor(idx, device=dev)].cpu().numpy()
+        par_obad = float((st_o != 0).sum())
+        par_mis = float((st_g != st_o).sum())
+    per_rank_rel, bad_total, obad_total, mis_total = [par_rel], par_bad, par_obad, par_mis
     if use_pg:
-        tt = torch.tensor([dt, ms_per_launch, dt_cold, ms_cold, par_rel, par_bad], dtype=torch.float64, device=cdev)
+        tt = torch.tensor([dt, ms_per_launch, dt_cold, ms_cold, par_rel, par_bad, par_obad, par_mis], dtype=torch.float64, device=cdev)
         parts = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(parts, tt)
         allr = torch.stack(parts).cpu().numpy()
         per_rank_kernel_ms = [float(x) for x in allr[:, 1]]
         per_rank_rel = [float(x) for x in allr[:, 4]]
-        bad_total = float(allr[:, 5].sum())
+        bad_total, obad_total, mis_total = (float(allr[:, c].sum()) for c in (5, 6, 7))
         dt, ms_per_launch, dt_cold, ms_cold = (float(x) for x in allr[:, :4].max(0))     # MAX over ranks
     # per-launch distribution (outside the timed region): one HIP event between every two launches
     each, _ = ctrl.time_steps_each(a.steps, q, v, tg, mask, mu, ms, out=out)
@@ -488,7 +492,7 @@ def run_rank(a):
         issued = None
         try:
             if shard["kind"] == "mptc" and cfg == 3 and n == 4096:
-                with open(os.path.join(ROOT, "profiles", "r04", "hex_pmc.json")) as f:
+                with open(os.path.join(ROOT, "profiles", PMC_ROUND, "hex_pmc.json")) as f:
                     pj = json.load(f)
                 if pj.get("kernel_src_sha16") != kernel_src_sha16():
                     raise KeyError("counter file is from another kernel build")
@@ -499,13 +503,16 @@ def run_rank(a):
                           "executed_frac_of_peak": ex / sec / 1e12 / PEAK_FP64_VALU_TFLOPS,
                           "redundancy": ex / (flops * n), "valu_insts_per_wavefront": g("SQ_INSTS_VALU") / g("SQ_WAVES"),
                           "mfma_insts": g("SQ_INSTS_MFMA"),
-                          "source": "profiles/r04/hex_pmc.json (rocprofv3 --pmc, separate passes of this command; same kernel "
+                          "source": "profiles/" + PMC_ROUND + "/hex_pmc.json (rocprofv3 --pmc, separate passes of this command; same kernel "
                                     "sources: sha16 %s)" % pj["kernel_src_sha16"]}
         except (OSError, ValueError, KeyError):
             pass
         line = {
             "metric": "whole-body-QP control ticks/s at N=4096 Mini Cheetah",
             "value": n_total * a.steps / dt, "unit": "ticks/s",
+            # the same K launches without the region's fixed cost (stream start-up, statistics reduction and gather, one wake-up: ~30 us,
+            # which weigh 1.5 us per step at the driver's K = 20 and 0.15 at K = 200): instances / slowest rank's HIP-event launch time
+            "value_kernel_only": n_total / (ms_per_launch * 1e-3),
             "value_cold": n_total * a.steps / dt_cold, "kernel_ms_cold": ms_cold,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -519,7 +526,8 @@ def run_rank(a):
                 "domain_randomised": mu is not None, "parallelism": "batch-shard x%d" % world},
             "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
-                         "kernel": "wbc_hex_kernel<%s>" % shard["kind"].upper(),
+                         "kernel": "wbc_hex_kernel<%d, false>" % {"id": 0, "mptc": 1, "pc": 2, "clf": 3}[shard["kind"]],   # the name rocprofv3 prints
+                         "kernel_law": shard["kind"].upper(),
                          "kernel_ms": ms_per_launch, "flops_per_tick": flops, "issued": issued,
                          "kernel_ms_dist": {"median": float(np.median(each)), "p10": float(np.percentile(each, 10)),
                                             "p90": float(np.percentile(each, 90)), "launches": int(each.size),
@@ -530,7 +538,9 @@ def run_rank(a):
                                          "the dense FP64 peak (78.6 TFLOP/s, the same figure for FP64 MFMA and FP64 VALU); the "
                                          "kernel issues v_fma_f64, not MFMA (profiles/r02/micro_mfma_f64.md)",
                          "note": "HBM does not bind this path (SURVEY 8d): 864 algorithmic bytes per 37.6 kflop tick; HBM fraction stated beside it"},
-            "status_nonzero": int(bad_total),                     # every rank's whole shard (+ its oracle sample), summed
+            "status_nonzero": int(bad_total),                     # instances with status != 0 on the device: every rank's whole shard, summed
+            "oracle_status_nonzero": (int(obad_total) if not a.no_cpu_baseline else None),    # the oracle's, on the parity samples
+            "status_mismatch": (int(mis_total) if not a.no_cpu_baseline else None),           # sample instances where device and oracle disagree
             "torque_rel_err_vs_cpu_ref": (max(per_rank_rel) if not a.no_cpu_baseline else None),
             "per_rank_torque_rel_err": (per_rank_rel if not a.no_cpu_baseline else None),
             "parity_sample": "64 instances spread over EVERY rank's shard against the oracle on that rank's host; maximum over ranks",

@@ -63,9 +63,10 @@ extern "C" {
 #define WBC_HOST_PTRS 1u   /* wbc_step receives host pointers; staged through handle-owned buffers (n <= 64: one pinned,
                               device-mapped block the kernel reads and writes directly, no copy calls).  The OUTPUT arrays of a
                               wbc_step must stay valid until the outputs have been delivered, and only the library delivers
-                              them: wbc_sync, or the next wbc_step / wbc_set_stream / wbc_destroy on the handle (each first
-                              collects a pending result).  Waiting on the stream or on an event of one's own does NOT: for
-                              n <= 64 the copy into the caller's arrays is host code that runs inside those calls */
+                              them: wbc_sync, or the next wbc_step / wbc_set_stream on the handle (each first collects a
+                              pending result).  Waiting on the stream or on an event of one's own does NOT: for n <= 64 the
+                              copy into the caller's arrays is host code that runs inside those calls.  wbc_destroy waits
+                              for the device but ABANDONS an uncollected result: it never writes into caller-owned memory */
 
 /* Kinematic tree + inertias, as produced by tools/compile_model.py from the reference's URDFs
  * (models/mini_cheetah/mini_cheetah_mesh.urdf, models/anymal_b_simple_description/urdf/anymal_drake.urdf):

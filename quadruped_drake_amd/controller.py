@@ -66,6 +66,7 @@ class BatchedController:
                  q_perm=None, act_perm=None, use_torch_stream=True, strict=False):
         self.strict = bool(strict)      # ControlLaw: raise on status 3 as well (default: warn and return the torques)
         self.last_status = 0
+        self.n_illcond = 0              # ControlLaw ticks flagged with status 3 so far (every one of them also warns)
         self.table = load_model(model) if isinstance(model, str) else model
         self.max_batch = int(max_batch)
         self.device = int(device)
@@ -320,7 +321,13 @@ class BatchedController:
         self.last_status = st
         if st == 3 and not self.strict:
             import warnings
-            warnings.warn("whole-body QP tick flagged with status 3 (%s)" % STATUS_TEXT[3], IllConditionedWarning, stacklevel=2)
+            # EVERY flagged tick is visible: Python's default filter shows a warning once per call site (keyed on text + line number
+            # in the module's __warningregistry__), which would silence a control loop after its first ill-conditioned tick -- so
+            # the text carries the running count and the call goes through warn_explicit with the count as its line number
+            self.n_illcond += 1
+            warnings.warn_explicit("whole-body QP tick flagged with status 3 (%s) [flagged tick #%d of this controller; "
+                                   "last_status / n_illcond]" % (STATUS_TEXT[3], self.n_illcond), IllConditionedWarning,
+                                   filename=__file__, lineno=self.n_illcond, module=__name__, registry={})
         elif st != 0:
             raise SolverError("whole-body QP failed with status %d (%s)" % (st, STATUS_TEXT.get(st, "unknown")), st, tau)
         self.V, self.err, self.res, self.Vdot = (float(x) for x in met)

@@ -37,6 +37,13 @@ extern double* g_gi_dump;   // analysis: [16][NV + 3] per robot = the active set
 #else
 #define WBC_GI_STAT(x) do { } while (0)
 #endif
+// host instantiations (tests, tools/host_tick.cpp) check the kernel's structural invariants; device code carries none of it
+#if !defined(__HIPCC__)
+#include <cassert>
+#define WBC_HOST_ASSERT(x) assert(x)
+#else
+#define WBC_HOST_ASSERT(x) do { } while (0)
+#endif
 #ifndef WBC_GI_FORCE_BAIL
 #ifdef WBC_DEV_FORCE_BAIL   // diagnostic device builds: every wavefront leaves the fast path at trip WBC_DEV_FORCE_BAIL
 #define WBC_GI_FORCE_BAIL(qc) ((qc) == WBC_DEV_FORCE_BAIL)
@@ -186,6 +193,13 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   }
   sh_ = sg * qo.leg_pairs(z) + mu_n * qo.leg_bcast(z, 2);
   const double npl = PC ? -vrow_own * pc_inv : 0.0;   // own entry of the dense row's normal
+#ifndef WBC_NO_DROP_REFINE
+  // Lane (0, 3) owns no row of J: its Jr[] carries y = Q'b through the reflections (the evaluation after a drop, below), and z there
+  // accumulates a meaningless y . d.  That is harmless only while every 16-lane reduction over Jr or z is masked off that lane: the
+  // dense row's normal, the torque rows' normals and the tolerance's |z| are zero there by construction -- checked on the host.
+  WBC_HOST_ASSERT(h != 3 || (vrow_own == 0.0 && npl == 0.0 && z == 0.0));
+  if (TB) { for (int c = 0; c < NZ; c++) WBC_HOST_ASSERT(hex_lane(c) != 3); }   // the torque rows read Jr / z of column lanes only
+#endif
   double Dpc[NV], spc = 0.0, dnpc = 0.0, u_pc = 0.0;
   bool act_pc = false;
   if (PC) {
@@ -679,6 +693,9 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   }
 #endif
   }   // generic
+#ifndef WBC_NO_DROP_REFINE
+  z = (h == 3) ? 0.0 : z;   // lane (0, 3): y . d garbage (see the entry check); no 16-lane reduction downstream may pick it up
+#endif
   *iters_out = iters;
   if (!done && status == ST_OK) status = ST_ITER;
   return status;

@@ -785,8 +785,9 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
 int wbc_destroy(wbc_handle h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
-  if (h->zpend.active) (void)zc_finish(h);   // a small-batch host-pointer tick still pending: its outputs are delivered, not dropped
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  h->zpend.active = false;   // a small-batch host-pointer tick that was never collected is ABANDONED: destroy writes nothing into caller-owned arrays
+                             // (a caller on an error path may already have freed them); wbc_sync before wbc_destroy delivers it
   void* bufs[] = {h->d_model, h->d_params, h->d_stats, h->s_q, h->s_v, h->s_tg, h->s_mu, h->s_ms,
                   h->s_tau, h->s_met, h->s_mask, h->s_status};
   for (void* b : bufs) if (b) (void)hipFree(b);

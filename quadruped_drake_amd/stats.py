@@ -44,14 +44,33 @@ def from_vector(vec):
     return out
 
 
+MAX_FIELD = FIELDS.index("tau_abs_max")
+
+
+def reduce_vectors_numpy(gathered):
+    """The same fold in numpy: every field summed, tau_abs_max the maximum."""
+    g = np.ascontiguousarray(gathered, dtype=np.float64).reshape(-1, NSTAT)
+    acc = g[0].copy()
+    for r in range(1, g.shape[0]):      # rank order, like wbc_stats_reduce (the sums then round identically)
+        acc += g[r]
+    acc[MAX_FIELD] = g[:, MAX_FIELD].max()
+    return from_vector(acc)
+
+
 def reduce_vectors(gathered):
     """wbc_stats_reduce of the C ABI on `world` gathered vectors ([world, 22]): the reduction a C caller with its own
-    ncclAllGather runs -- the Python mirror goes through the same function."""
+    ncclAllGather runs -- the Python mirror goes through the same function.  This is 22 additions on the host and no part of
+    the hot path: a host-only rank without the HIP extension (gloo dry runs, CPU tests before build()) folds in numpy instead
+    (tests/test_abi_cpu.py holds the two equal)."""
     import ctypes as C
     from . import _lib
     g = np.ascontiguousarray(gathered, dtype=np.float64).reshape(-1, NSTAT)
+    try:
+        L = _lib.lib()
+    except (_lib.WbcError, OSError):
+        return reduce_vectors_numpy(g)
     out = _lib.WbcStats()
-    _lib.check(_lib.lib().wbc_stats_reduce(g.ctypes.data_as(_lib.c_double_p), int(g.shape[0]), C.byref(out)))
+    _lib.check(L.wbc_stats_reduce(g.ctypes.data_as(_lib.c_double_p), int(g.shape[0]), C.byref(out)))
     d = {k: float(getattr(out, k)) for k in FIELDS}
     d["mask_count"] = [float(x) for x in out.mask_count]
     return d

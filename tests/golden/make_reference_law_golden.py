@@ -170,13 +170,18 @@ from oracle import traj_oracle as to_      # noqa: E402
 sys.path.insert(0, ROOT)
 from planners.simple import BasicTrunkPlanner   # noqa: E402  (reference code)
 bp = BasicTrunkPlanner({"trunk": 0, "lf": 1, "rf": 2, "lh": 3, "rh": 4})
-for kind, dt, t_start in (("id", 5e-3, 0.85), ("mptc", 1e-3, 0.97)):
+for kind, dt, t_start in (("id", 5e-3, 0.85), ("mptc", 1e-3, 0.97), ("pc", 1e-3, 0.97), ("clf", 5e-3, 0.85)):
     plant = fake.RefPlant("mini_cheetah", body_frame="body")
     ctrl = LAWS[kind](plant, dt)
     steps = 60
     # start from a state already shifted over the support triangle (what the scenario has reached by then)
     q = q0.copy(); q[4:7] = [-0.1, 0.05, 0.3]; v = v0.copy()
-    Q, V, T, TAU = [q.copy()], [v.copy()], [], []
+    if kind == "pc":
+        # a start velocity under which the passivity row Vdot <= 0 (pc_controller.py:229-237) becomes ACTIVE in closed loop -- ticks
+        # 47 .. 59 of the window, after the contact switch (with v = 0 it never is and the trajectory equals MPTC's bit for bit)
+        rng_pc = np.random.default_rng(329)
+        v[:3] = rng_pc.normal(0, 1.0, 3); v[3:6] = rng_pc.normal(0, 0.6, 3); v[6:] = rng_pc.normal(0, 2.0, 12)
+    Q, V, T, TAU, VD = [q.copy()], [v.copy()], [], [], []
     for k in range(steps):
         t = t_start + k * dt
         bp.RaiseFoot(t)
@@ -188,10 +193,11 @@ for kind, dt, t_start in (("id", 5e-3, 0.85), ("mptc", 1e-3, 0.97)):
         vd = OsqpSolver.last["x"][:18]
         qn, vn = to_.integrate(q[:, None], v[:, None], vd[:, None], dt)
         q, v = qn[:, 0], vn[:, 0]
-        Q.append(q.copy()); V.append(v.copy()); T.append(t); TAU.append(np.array(tau))
+        Q.append(q.copy()); V.append(v.copy()); T.append(t); TAU.append(np.array(tau)); VD.append(float(ctrl.Vdot))
     pn = "closedloop_" + kind
     gold[pn + "_dt"] = dt; gold[pn + "_times"] = np.array(T)
     gold[pn + "_q"] = np.array(Q).T; gold[pn + "_v"] = np.array(V).T; gold[pn + "_tau"] = np.array(TAU).T
+    gold[pn + "_vdot_metric"] = np.array(VD)
     print("%-22s %d ticks from t = %.3f, dt = %g: RF foot contact %s -> %s, |v|max %.3f" %
           (pn, steps, t_start, dt, True, bool(d["contact_states"][1]), np.abs(np.array(V)).max()))
 

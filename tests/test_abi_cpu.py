@@ -52,6 +52,7 @@ def test_stats_reduce_folds_gathered_vectors_without_a_gpu():
     red = stats.reduce_vectors(g)
     assert red["tau_abs_max"] == g[:, 4].max() and abs(red["ticks"] - g[:, 0].sum()) < 1e-9 and red["mask_count"][15] == pytest.approx(g[:, 21].sum())
     assert per_rank[2]["err_sum"] == g[2, 5]
+    assert stats.reduce_vectors_numpy(g) == red                 # the host-only fallback of stats.reduce_vectors: same fold, same bits
     assert l.wbc_stats_reduce(None, 1, C.byref(out)) < 0 and l.wbc_stats_reduce(g.ctypes.data_as(_lib.c_double_p), 0, C.byref(out)) < 0
     assert l.wbc_stats_pack(None, g.ctypes.data_as(_lib.c_double_p)) < 0
 
@@ -152,3 +153,70 @@ def test_dpp_hazard_lint_flags_a_violation_and_passes_clean_code(tmp_path):
     r = subprocess.run([sys.executable, tool, str(spill)], capture_output=True, text=True)
     assert r.returncode == 1 and "_Zk: 96 B/lane" in r.stdout
     assert subprocess.run([sys.executable, tool, str(ok)], capture_output=True).returncode == 0
+
+
+def test_headers_compile_as_c99_and_struct_layouts_equal_the_ctypes_mirrors(tmp_path):
+    """include/wbc.h and include/wbc_extras.h are C headers (`gcc -std=c99 -Wall -pedantic`), and every struct the ctypes
+    mirror in quadruped_drake_amd/_lib.py re-declares by hand has the same size and the same offset for every field: a member
+    added on one side only would otherwise be a silent mis-read across the boundary."""
+    import subprocess
+    from quadruped_drake_amd import _lib
+    mirrors = {"wbc_model": _lib.WbcModel, "wbc_params": _lib.WbcParams, "wbc_stats": _lib.WbcStats,
+               "wbc_trunk_state": _lib.WbcTrunkState, "wbc_robot_state": _lib.WbcRobotState}
+    lines = []
+    for cname, cls in mirrors.items():
+        lines.append('printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f, _ in cls._fields_:
+            lines.append('printf("%s %s %%zu %%zu\\n", offsetof(%s, %s), sizeof(((%s*)0)->%s));' % (cname, f, cname, f, cname, f))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "wbc.h"\n#include "wbc_extras.h"\n'
+                   'int main(void) {\n  printf("NSTAT %d\\n", WBC_NSTAT);\n  ' + "\n  ".join(lines) + "\n  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)],
+                   check=True, capture_output=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    seen = {k: set() for k in mirrors}
+    for ln in out:
+        w = ln.split()
+        if not w:
+            continue
+        if w[0] == "NSTAT":
+            assert int(w[1]) == 22 == C.sizeof(_lib.WbcStats) // 8
+        elif w[1] == "sizeof":
+            assert int(w[2]) == C.sizeof(mirrors[w[0]]), ln
+        else:
+            fld = getattr(mirrors[w[0]], w[1])
+            assert (int(w[2]), int(w[3])) == (fld.offset, fld.size), ln
+            seen[w[0]].add(w[1])
+    # ... and the other way round: every member the C struct declares is mirrored (member names parsed from the headers)
+    hdr = open(os.path.join(ROOT, "include", "wbc.h")).read() + open(os.path.join(ROOT, "include", "wbc_extras.h")).read()
+    for cname, cls in mirrors.items():
+        body = re.search(r"typedef struct \{([^}]*)\}\s*%s;" % cname, hdr).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        members = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                members += [re.match(r"\**\s*([A-Za-z_0-9]+)", m.strip().split(" ")[-1]).group(1) for m in decl.split(",")]
+        assert sorted(members) == sorted(f for f, _ in cls._fields_) == sorted(seen[cname]), (cname, members)
+
+
+def test_window_generation_equals_sharding_the_whole_batch():
+    """What every rank of a multi-GPU run generates (workloads.make_batch(..., window=shard_range(...))) is bit for bit the
+    rank's shard of the whole batch (stats.shard_batch): BASELINE config 5, N = 32768 over 8 ranks; and a ragged split."""
+    from quadruped_drake_amd import stats, workloads
+    for cfg, n, world in ((5, 32768, 8), (3, 1003, 3)):
+        whole = workloads.make_batch(cfg, n=n)
+        covered = 0
+        for r in range(world):
+            lo, hi = stats.shard_range(n, r, world)
+            win = workloads.make_batch(cfg, n=n, window=(lo, hi))
+            ref = stats.shard_batch(whole, r, world)
+            assert win["n"] == ref["n"] == hi - lo and win["n_total"] == n and win["window"] == (lo, hi)
+            for k in ("q", "v", "targets", "mask", "mu", "mass_scale"):
+                if ref[k] is None:
+                    assert win[k] is None
+                else:
+                    assert win[k].dtype == ref[k].dtype and np.array_equal(win[k], ref[k]), (cfg, r, k)
+            covered += hi - lo
+        assert covered == n

@@ -228,7 +228,11 @@ def test_host_pointer_small_batch_goes_through_the_mapped_block():
     host.sync()
     assert np.array_equal(t2[:, :n], tau_d[:, 8:8 + n]) and np.array_equal(m2[:, :n], met_d[:, 8:8 + n]) and np.array_equal(s2[:n], st_d[8:8 + n])
     assert (t2[:, n:] == 0).all() and (s2[n:] == -1).all()
+    # wbc_destroy ABANDONS a result that was never collected: it waits for the device and writes nothing into caller-owned arrays
+    t3 = np.zeros((12, 64))
+    _lib.check(L.wbc_step(host._h, n, 64, p(q), p(v), p(tg), p(b["mask"]), p(b["mu"]), p(b["mass_scale"]), p(t3), None, None))
     host.close()
+    assert (t3 == 0).all()
 
 
 @pytest.mark.parametrize("kind", ["mptc", "pc", "id", "clf"])
@@ -356,6 +360,13 @@ def test_ill_conditioned_ticks_are_reported_not_hidden():
     with pytest.warns(IllConditionedWarning):
         u = c.ControlLaw(q[:, 0], b["v"][:, 0], d)
     assert c.last_status == 3 and np.isfinite(u).all() and np.abs(u).max() > 0
+    # ... on EVERY flagged tick of a control loop, not once per call site (Python's default filter), and counts them
+    import warnings
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("default")
+        for _ in range(3):
+            c.ControlLaw(q[:, 0], b["v"][:, 0], d)
+    assert len([w for w in rec if issubclass(w.category, IllConditionedWarning)]) == 3 and c.n_illcond == 4
     c.close()
     # ... unless asked to be strict
     c = MPTCController(max_batch=1, device=0, strict=True)

@@ -287,3 +287,29 @@ def test_swing_row_compaction_changes_no_bit(tmp_path):
         tau_c, met_c, st_c, it_c = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], mk, hexv=True)
         assert (st == 0).all() and (st_c == 0).all() and np.array_equal(it, it_c)
         assert np.array_equal(tau_c, tau) and np.array_equal(met_c, met)
+
+
+@pytest.mark.parametrize("kind,tmax", [("pc", None), ("id", 8.0), ("pc", 8.0), ("mptc", 8.0)])
+def test_evaluation_after_a_drop_with_inhomogeneous_rows_on_host(kind, tmax):
+    """The evaluation after a drop (csrc/wbc_hex.hpp, end of hex_gi) has a branch for INHOMOGENEOUS active rows -- the PC law's dense
+    row Vdot <= 0 and the torque box's rows put g = sum beta_a W_a into the used slots -- which the ID stands of the test above never
+    enter.  4-contact stands (drop-heavy: 10 - 19 trips per robot) under the PC law and under a box of 8 N m that binds on most of
+    them, against the oracle compiled in extended precision: within 2e-7 (measured 2e-8 .. 8e-8), every status equal.  Runs the
+    host instantiation, whose asserts also check that lane (0, 3) -- which carries y = Q'b in its row slots -- contributes
+    nothing to any 16-lane reduction."""
+    from oracle import oracle_ld as old
+    b = workloads.make_batch(2, n=256, seed=50002)
+    pl = old.params(kind)
+    po = orc.params(kind)
+    names = ("Kp_body_p", "Kd_body_p", "Kp_body_rpy", "Kd_body_rpy", "Kp_foot", "Kd_foot", "w_body", "w_foot", "mu", "Kd_contact",
+             "tau_max", "tiebreak_eps2")
+    pp = np.array([getattr(po, k) for k in names])
+    if tmax is not None:
+        pl.tau_max = tmax; pp[10] = tmax
+    tau_l, _, st_l = old.step_batch(kind, old.model(b["model"]), pl, b["q"], b["v"], b["targets"], b["mask"])
+    tau, _, st, it = ht.run(kind, orc.load_model_json(b["model"])["flat"], b["q"], b["v"], b["targets"], b["mask"], params12=pp, hexv=True)
+    assert np.array_equal(st, st_l) and (st == 0).all()
+    assert it.mean() > 8                                                       # drop-heavy: the branch is exercised
+    assert rel_err(tau, tau_l.astype(np.float64)).max() < 2e-7
+    if tmax is not None:
+        assert (np.abs(tau).max(0) > tmax * (1 - 1e-9)).sum() > 100 and np.abs(tau).max() <= tmax * (1 + 1e-9)

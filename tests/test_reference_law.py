@@ -149,7 +149,17 @@ def _closed(kind):
     return float(z[p + "dt"]), z[p + "times"], z[p + "q"], z[p + "v"], z[p + "tau"]
 
 
-@pytest.mark.parametrize("kind", ["id", "mptc"])
+def test_closed_loop_pc_fixture_has_the_passivity_row_active():
+    """The PC trajectory is not the MPTC one in disguise: the reference's logged Vdot (pc_controller.py:229-237, the row
+    Vdot <= delta <= 0) sits AT zero on a run of ticks after the contact switch, and below zero before."""
+    z = np.load(os.path.join(HERE, "golden", "reference_law_golden.npz"))
+    vd, T = z["closedloop_pc_vdot_metric"], z["closedloop_pc_times"]
+    at = np.abs(vd) < 1e-9
+    assert at.sum() >= 10 and (T[at] > 1).all() and (vd[~at] < -1e-3).all() and (vd < 1e-9).all()
+    assert not np.array_equal(z["closedloop_pc_q"], z["closedloop_mptc_q"])
+
+
+@pytest.mark.parametrize("kind", ["id", "mptc", "pc", "clf"])
 def test_closed_loop_oracle_follows_the_executed_reference(kind):
     """Reference planner scenario (RaiseFoot across its contact switch) -> reference controller code -> forward step,
     60 ticks (make_reference_law_golden.py): the oracle's tick + the numpy integrator retrace the same trajectory."""
@@ -170,18 +180,18 @@ def test_closed_loop_oracle_follows_the_executed_reference(kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["id", "mptc"])
+@pytest.mark.parametrize("kind", ["id", "mptc", "pc", "clf"])
 def test_device_rollout_follows_the_executed_reference(kind):
     """wbc_rollout (stored-trajectory lookup -> tick -> forward step, one persistent launch per chunk) against the same
     trajectory: the whole closed-loop chain of the device against the reference's executed planner + controller code."""
     import torch
-    from quadruped_drake_amd import IDController, MPTCController
+    from quadruped_drake_amd import IDController, MPTCController, PCController, CLFController
     from quadruped_drake_amd.planners import scenario_targets
     from quadruped_drake_amd.trajectory import TrunkTrajectory
     dt, T, Q, V, TAU = _closed(kind)
     tg, mk = scenario_targets("raise_foot", T)
     traj = TrunkTrajectory(T, np.ascontiguousarray(tg.T), mk, wait_time=0.0, device=0)
-    ctrl = {"id": IDController, "mptc": MPTCController}[kind](max_batch=4, device=0)
+    ctrl = {"id": IDController, "mptc": MPTCController, "pc": PCController, "clf": CLFController}[kind](max_batch=4, device=0)
     q = torch.tensor(np.tile(Q[:, :1], (1, 4)), device="cuda:0"); v = torch.tensor(np.tile(V[:, :1], (1, 4)), device="cuda:0")
     time = torch.full((4,), float(T[0]), dtype=torch.float64, device="cuda:0")
     for c in range(6):

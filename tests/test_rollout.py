@@ -205,13 +205,17 @@ def _trot_trajectory(K=300, dt=1e-3, seed=7):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["mptc", "id"])
-def test_persistent_rollout_equals_launch_per_stage(kind):
+@pytest.mark.parametrize("box", [False, True])
+@pytest.mark.parametrize("kind", ["mptc", "id", "pc", "clf"])
+def test_persistent_rollout_equals_launch_per_stage(kind, box):
     """wbc_rollout on the 16-lane mapping is ONE persistent launch (state in LDS between ticks, lookup with an
     index hint, in-kernel forward step); it must reproduce the launch-per-stage loop (wbc_traj_lookup, wbc_step,
-    wbc_integrate, time += dt) bit for bit -- contact switches, per-robot time offsets and the wait phase included."""
+    wbc_integrate, time += dt) bit for bit -- contact switches, per-robot time offsets and the wait phase included.
+    All EIGHT instantiations wbc_rollout dispatches (four laws x torque box off / on: each has its own register allocation,
+    462 - 488 registers) against the tick kernels of the same law and option.  The box (6 N m under the task-space laws, 12 N m under
+    the ID-type ones: what binds on about half of this rollout's ticks and stays feasible -- host emulation) must really bind."""
     import torch
-    from quadruped_drake_amd import IDController, MPTCController
+    from quadruped_drake_amd import IDController, MPTCController, PCController, CLFController
     from quadruped_drake_amd.trajectory import TrunkTrajectory
     n, steps, dt = 203, 120, 1e-3
     ts, tg, masks, st_t = _trot_trajectory()
@@ -220,19 +224,22 @@ def test_persistent_rollout_equals_launch_per_stage(kind):
     rng = np.random.default_rng(11)
     q0[7:] += rng.uniform(-0.05, 0.05, (12, n)); v0[0:6] = rng.normal(0, 0.05, (6, n))
     t0 = rng.uniform(0.0, 0.25, n)                       # some robots start inside the wait phase, some past the table's end
-    cls = MPTCController if kind == "mptc" else IDController
+    cls = {"mptc": MPTCController, "id": IDController, "pc": PCController, "clf": CLFController}[kind]
+    tau_max = {"mptc": 6.0, "pc": 6.0, "id": 12.0, "clf": 12.0}[kind] if box else None
+    prm = None if tau_max is None else {"tau_max": tau_max}
     dev = "cuda:0"
     # (a) persistent
-    ca = cls(max_batch=n, device=0); ca.set_variant("hex")
+    ca = cls(max_batch=n, device=0, params=prm); ca.set_variant("hex")
     qa = torch.tensor(q0, device=dev); va = torch.tensor(v0, device=dev); ta = torch.tensor(t0, device=dev)
     tau_a, met_a, st_a, tg_a, mk_a = ca.rollout(traj, steps, dt, qa, va, ta)
     ca.sync()
     sa = ca.stats()
     # (b) one launch per stage, same kernels' arithmetic
-    cb = cls(max_batch=n, device=0); cb.set_variant("hex")
+    cb = cls(max_batch=n, device=0, params=prm); cb.set_variant("hex")
     qb = torch.tensor(q0, device=dev); vb = torch.tensor(v0, device=dev); tb = torch.tensor(t0, device=dev)
     vd = torch.zeros((18, n), dtype=torch.float64, device=dev)
     cb.set_vdot_output(vd)
+    tbox_active = 0
     for _ in range(steps):
         tg_b, mk_b = traj.lookup(tb)
         torch.cuda.synchronize()
@@ -240,7 +247,11 @@ def test_persistent_rollout_equals_launch_per_stage(kind):
         cb.integrate(qb, vb, vd, dt)
         cb.sync()
         tb += dt
+        if tau_max is not None:
+            tbox_active += int((tau_b.abs().max(0).values > tau_max * (1 - 1e-9)).sum())
     sb = cb.stats()
+    if tau_max is not None:
+        assert float(tau_b[:, st_b == 0].abs().max()) <= tau_max * (1 + 1e-9) and tbox_active > steps * n // 10     # the box binds along the rollout
     for a, b in ((qa, qb), (va, vb), (ta, tb), (tau_a, tau_b), (met_a, met_b), (tg_a, tg_b)):
         assert np.array_equal(a.cpu().numpy(), b.cpu().numpy())
     assert np.array_equal(st_a.cpu().numpy(), st_b.cpu().numpy()) and np.array_equal(mk_a.cpu().numpy(), mk_b.cpu().numpy())
