@@ -58,6 +58,14 @@ def kernel_src_sha16():
     return h.hexdigest()[:16]
 
 
+def fnv1a64(data):
+    """FNV-1a, 64 bit, over a bytes object (examples/wbc_host.cpp: fnv1a64)."""
+    h = 1469598103934665603
+    for c in data:
+        h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -455,15 +463,22 @@ def run_rank(a):
         st_g = out[2][torch.tensor(idx, device=dev)].cpu().numpy()
         par_obad = float((st_o != 0).sum())
         par_mis = float((st_g != st_o).sum())
+    # checksum of this rank's torques of the last launch: FNV-1a 64 over the [12][n] doubles -- what examples/wbc_host.cpp prints for
+    # the same shard (two hosts, one library: the same bits)
+    tau_bytes = out[0].cpu().numpy().tobytes()
+    tau_hash = fnv1a64(tau_bytes)
     per_rank_rel, bad_total, obad_total, mis_total = [par_rel], par_bad, par_obad, par_mis
+    per_rank_hash = ["%016x" % tau_hash]
     if use_pg:
-        tt = torch.tensor([dt, ms_per_launch, dt_cold, ms_cold, par_rel, par_bad, par_obad, par_mis], dtype=torch.float64, device=cdev)
+        tt = torch.tensor([dt, ms_per_launch, dt_cold, ms_cold, par_rel, par_bad, par_obad, par_mis, float(tau_hash >> 32), float(tau_hash & 0xffffffff)],
+                          dtype=torch.float64, device=cdev)
         parts = [torch.empty_like(tt) for _ in range(world)]
         dist.all_gather(parts, tt)
         allr = torch.stack(parts).cpu().numpy()
         per_rank_kernel_ms = [float(x) for x in allr[:, 1]]
         per_rank_rel = [float(x) for x in allr[:, 4]]
         bad_total, obad_total, mis_total = (float(allr[:, c].sum()) for c in (5, 6, 7))
+        per_rank_hash = ["%016x" % ((int(allr[r, 8]) << 32) | int(allr[r, 9])) for r in range(world)]
         dt, ms_per_launch, dt_cold, ms_cold = (float(x) for x in allr[:, :4].max(0))     # MAX over ranks
     # per-launch distribution (outside the timed region): one HIP event between every two launches
     each, _ = ctrl.time_steps_each(a.steps, q, v, tg, mask, mu, ms, out=out)
@@ -519,6 +534,7 @@ def run_rank(a):
             "dtype": "f64", "data": "synthetic", "backend": a.backend, "ramp_seconds": a.ramp_seconds,
             "ranks_seen": seen, "per_rank_ticks": [r["ticks"] for r in per_rank], "per_rank_kernel_ms": per_rank_kernel_ms,
             "process_group": (a.backend if use_pg else None), "kernel_src_sha16": kernel_src_sha16(),
+            "per_rank_tau_fnv1a64": per_rank_hash,
             "config": {"workload": "BASELINE configs[%d]: %d x %s, %s controller, %s" % (
                 cfg - 1, n_total, shard["model"], shard["kind"].upper(),
                 "trot contact masks" if cfg != 2 else "4-contact stand"),

@@ -104,3 +104,35 @@ def make_batch(config, n=None, seed=None, model=None, window=None):
         out["mu"] = np.ascontiguousarray(cut(rng.uniform(0.4, 1.0, n)))
         out["mass_scale"] = np.ascontiguousarray(cut(rng.uniform(0.8, 1.2, n)))
     return out
+
+
+def dump_batch(path, batch, model_table=None):
+    """The batch as ONE little-endian binary file for a host without Python (examples/wbc_host.cpp reads it):
+    "WBCBATCH" | int32 version = 1, kind, n, has_mu | wbc_model (flat[215] doubles, q_perm[12], act_perm[12] int32) |
+    q[19][n] v[18][n] targets[54][n] doubles, batch index fastest | mask[n] bytes, zero-padded to a multiple of 8 |
+    [mu[n] mass_scale[n] doubles]."""
+    import json
+    import os
+    if model_table is None:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "models", batch["model"] + ".json")) as f:
+            model_table = json.load(f)
+    n = int(batch["n"])
+    kind = {"id": 0, "mptc": 1, "pc": 2, "clf": 3}[batch["kind"]]
+    has_mu = batch["mu"] is not None
+    with open(path, "wb") as f:
+        f.write(b"WBCBATCH")
+        f.write(np.array([1, kind, n, int(has_mu)], dtype="<i4").tobytes())
+        f.write(np.asarray(model_table["flat"], dtype="<f8").tobytes())
+        f.write(np.arange(12, dtype="<i4").tobytes())
+        f.write(np.asarray(model_table.get("act_perm", range(12)), dtype="<i4").tobytes())
+        for k, rows in (("q", 19), ("v", 18), ("targets", 54)):
+            a = np.ascontiguousarray(batch[k], dtype="<f8")
+            assert a.shape == (rows, n)
+            f.write(a.tobytes())
+        mk = np.zeros((n + 7) // 8 * 8, dtype=np.uint8)
+        mk[:n] = batch["mask"]
+        f.write(mk.tobytes())
+        if has_mu:
+            f.write(np.ascontiguousarray(batch["mu"], dtype="<f8").tobytes())
+            f.write(np.ascontiguousarray(batch["mass_scale"], dtype="<f8").tobytes())
+    return path
