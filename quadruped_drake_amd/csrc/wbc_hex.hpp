@@ -155,6 +155,29 @@ WBC_HD int hex_key_index(double k) {
   __builtin_memcpy(&b, &k, 8);
   return (int)(b & 31ull);
 }
+// The PICK keys (most violated row / greatest dual gain) are packed coarsely: the low 24 mantissa bits are replaced, i.e. candidates within 6e-8
+// of each other count as tied and the LOWER row index wins (the keys that matter are negative: a larger low field is a larger magnitude,
+// hence 31 - idx).  Why: on the way into an apex of a friction pyramid -- one x-side and one y-side row of a foot active -- the foot's two
+// remaining rows have EXACTLY the same value (2 mu_n f_z) and the same free part, so rounding used to decide the pick, differently on the host and on the
+// device and from build to build, and one of the two choices ends in a blocked step: a drop and a re-add, on the device two generic trips for
+// the whole wavefront (the slowest wavefront of the headline launch was such a robot; profiles/r05/apex_rule.md).  The pick only needs
+// SOME violated row, the exact value of the picked row is fetched from its lane; the blocking-ratio keys (hex_pack_key) stay at 2^-47.
+#ifndef WBC_PICK_BITS
+#define WBC_PICK_BITS 24
+#endif
+template <int BITS = WBC_PICK_BITS> WBC_HD double hex_pack_pick(double v, int idx) {
+  unsigned long long b;
+  __builtin_memcpy(&b, &v, 8);
+  b = (b & ~((1ull << BITS) - 1ull)) | (unsigned long long)((31 - idx) & 31);
+  double k;
+  __builtin_memcpy(&k, &b, 8);
+  return k;
+}
+WBC_HD int hex_pick_index(double k) {
+  unsigned long long b;
+  __builtin_memcpy(&b, &k, 8);
+  return 31 - (int)(b & 31ull);
+}
 
 // Goldfarb-Idnani on the friction rows, register-resident "constraint-space" form.
 //
@@ -229,6 +252,25 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     for (int k = 0; k < NV; k++) dnt += Dt[k] * Dt[k];
   }
   int q = 0, iters = 0, status = ST_OK;
+  // The APEX rule (profiles/r05/apex_rule.md).  The four friction rows of a foot satisfy n_0 + n_1 = n_2 + n_3 (= 2 mu_n e_z): while three of them
+  // are active the fourth is linearly dependent and its value is identically zero -- in floating point a rounding remainder of either sign.  A
+  // negative remainder beyond the tolerance used to be picked, found dependent, and cost a drop and an add (on the device: two GENERIC trips and the
+  // fast path lost for the whole wavefront) that swap one description of the apex for another; on BASELINE config 2, whose solutions sit on
+  // edges and apexes, that was one trip in ten, and three of the six slowest wavefronts of the headline launch.  A row whose three leg-mates are
+  // active is therefore not a candidate.  nleg = active friction rows of the own leg (replicated on its four lanes).
+  // (Friction-only instantiations -- ID, MPTC, with or without the torque box: the dense-row laws PC / CLF carry their Dpc / Wpc arrays through the same
+  // trips and measured 2 % slower with the bookkeeping than they gain -- their picks still get the deterministic tie-break of hex_pack_pick.)
+#ifndef WBC_NO_APEX_RULE
+  constexpr bool APEX = !PC;
+#else
+  constexpr bool APEX = false;
+#endif
+  // dense-row laws: the keys of rounds 1-4 unchanged (anything else costs the CLF torque-box rollout kernel, at 486 registers, its last ones: 8 B/lane of scratch)
+  auto pick_pack = [](double v, int idx) -> double { if constexpr (PC) return hex_pack_key(v, idx); else return hex_pack_pick<WBC_PICK_BITS>(v, idx); };
+  auto pick_pack_fine = [](double v, int idx) -> double { if constexpr (PC) return hex_pack_key(v, idx); else return hex_pack_pick<5>(v, idx); };
+  auto pick_index = [](double k) -> int { if constexpr (PC) return hex_key_index(k); else return hex_pick_index(k); };
+  int nleg = 0;
+  auto same_leg = [&](int row) -> int { return (((row ^ h) & 12) == 0) ? 1 : 0; };   // friction row `row` (0..15, robot-uniform) belongs to my leg
   const int maxit = 200;
   bool done = false, need_pick = true, picked = false;
   int p = -1;
@@ -264,17 +306,17 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       int pf;
       {
         double key = HEX_NONE;
-        if (!done && ct && !act_h) {
+        if (!done && ct && !act_h && !(APEX && nleg == 3)) {
           if (GAIN) {
             double dd2 = 0.0;
             static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; dd2 = fmad(Dh[k], Dh[k], dd2); });
-            if (sh_ < -tol) key = hex_pack_key((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
+            if (sh_ < -tol) key = pick_pack((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
           } else {
-            key = hex_pack_key(sh_, h);
+            key = pick_pack(sh_, h);
           }
         }
         key = qo.min16(key);
-        pf = (key < 1e299) ? hex_key_index(key) : -1;
+        pf = (key < 1e299) ? pick_index(key) : -1;
       }
       // PC law: the dense row (Vdot <= 0) is never added here -- a robot whose dense row is violated sends the wavefront to the
       // generic loop (rare: ~5 % of the robots); while it is inactive the fast trips only carry its image and value along
@@ -351,6 +393,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         Wr[qc] = mine ? ia : -r_h * ia;
         u_h = mine ? t2 : u_h;
         act_h = act_h || mine;
+        if (APEX) nleg += same_leg(pf);
         q = qc + 1;
       }
     });
@@ -393,17 +436,17 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
             for (int k = 0; k < NV; k++) dd2 = fmad(mk[k] * Dh[k], Dh[k], dd2);
             // a violated row whose image has no free part (linearly dependent on the active ones) must still be
             // picked -- the dependent-step logic below resolves or reports it -- so it gets the largest finite gain
-            if (ct && !act_h && sh_ < -tol)
-              key = hex_pack_key((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
+            if (ct && !act_h && !(APEX && nleg == 3) && sh_ < -tol)
+              key = pick_pack((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
           } else {
-            if (ct && !act_h) key = hex_pack_key(sh_, h);
+            if (ct && !act_h && !(APEX && nleg == 3)) key = pick_pack(sh_, h);
           }
           if (TB) {
             const double st_ = bt - fabs(yt);
-            if (elig_t && !act_t && st_ < key) key = hex_pack_key(st_, 16 + h);
+            if (elig_t && !act_t && st_ < key) key = pick_pack_fine(st_, 16 + h);   // a torque row's key IS its value downstream (no fetch): 2^-47, as before
           }
           key = qo.min16(key);
-          const int ix = hex_key_index(key);
+          const int ix = pick_index(key);
           sp = key;
           p = (key < 1e299) ? ((ix < 16) ? ix : 16 + ix) : -1;   // torque slot ids are 32 + lane
           if (p < 0) sp = INF;
@@ -422,7 +465,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       if (TB) sg_x = qo.bcast16d((yt > 0.0) ? -1.0 : 1.0, pl);
       if (picked) {
         picked = false;
-        if (p >= 0 && p < 16) sp = sp_x;
+        if (p >= 0 && p < 16) sp = sp_x;   // (the friction rows' pick keys are coarse, hex_pack_pick: the exact value comes from the row's lane)
         if (pc && !act_pc && spc < sp) { sp = spc; p = 16; }
         if (!(sp < -tol)) p = -1;
         if (p < 0) {
@@ -613,6 +656,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       }
       u_h = mined ? 0.0 : u_h;
       act_h = act_h && !mined;
+      if (APEX) nleg -= (drop && hd >= 0 && hd < 16) ? same_leg(hd) : 0;
       if (TB) { u_t = tmd ? 0.0 : u_t; act_t = act_t && !tmd; }
       if (PC) { u_pc = pmd ? 0.0 : u_pc; act_pc = act_pc && !pmd; }
     }
@@ -624,6 +668,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       for (int k = 0; k < NV; k++) Wr[k] = fmad(eq[k], wq, Wr[k]);
       u_h = mine ? up : u_h;
       act_h = act_h || mine;
+      if (APEX) nleg += (full && p >= 0 && p < 16) ? same_leg(p) : 0;
       if (TB) {
         const bool tm = full && (p == 32 + h);
         const double wqt = full ? (tm ? ia : -r_t * ia) : 0.0;

@@ -359,6 +359,9 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* __restric
   __shared__ double inbuf[PER_LANE * HEX_BLOCK];                      // 91 rows x 4 robots, padded to whole lanes
   __shared__ double parkbuf[HROBOTS * wbc::PK_N];
   __shared__ double lanebuf[wbc::LP_N * HEX_BLOCK];
+#ifdef WBC_PAD   // diagnostic: shift the kernel body by WBC_PAD instructions (code-placement sensitivity, profiles/r05/code_placement.md)
+  asm volatile(".rept %0\n\ts_nop 0\n\t.endr" :: "n"(WBC_PAD));
+#endif
   WBC_STAMP(0);
 #ifdef WBC_STAMPS   // where this wavefront runs: HW_ID (cu / simd / se) and XCC_ID
   if (threadIdx.x == 0) {

@@ -4,7 +4,7 @@
 #   PMC passes (separate runs; --pmc is never combined with sys/hip traces) for the headline MPTC kernel, for the ID kernel on
 #   BASELINE config 2, and the HBM-traffic counters for the three bench shapes, batch-size sweeps, tail experiment, rollout.
 # Under rocprofv3 the program itself follows `--` (python3 <script>): no env / bash -c / launcher hop.
-tag=${1:-r04}; out=gpurun_out/$tag; mkdir -p $out; root=$PWD
+tag=${1:-r05}; out=gpurun_out/$tag; mkdir -p $out; root=$PWD
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1
 python bench.py > $out/bench.json 2> $out/bench.err
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $root/$out/stats -o run --output-format csv -- python3 $root/bench.py --no-cpu-baseline --steps 200 > $root/$out/stats.log 2>&1 )
@@ -31,4 +31,13 @@ bash tools/sweep_n.sh 2 hex > $out/sweep_id.txt 2>&1
 python3 tools/tail_exp.py > $out/tail_experiment.txt 2>&1
 python3 tools/rollout_bench.py > $out/rollout.txt 2>&1
 python3 tools/singular_sweep.py > $out/singular_envelope.md 2> $out/singular.err
+# round 5: the driver's own invocation (K = 20) beside the 200-step line; the C++ host on the same batch; where the launch's tail comes from
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_k20.json 2> $out/bench_k20.err
+python bench.py --config 5 --per-gpu 4096 --no-cpu-baseline > $out/bench_cfg5.json 2> $out/bench_cfg5.err
+python3 -c "from quadruped_drake_amd import workloads as w; w.dump_batch('/tmp/cfg5_4096.bin', w.make_batch(5, n=4096))" && ./examples/wbc_host --batch /tmp/cfg5_4096.bin --gpus 1 --steps 200 --warmup 20 --repeat 5 > $out/wbc_host.json 2> $out/wbc_host.err
+if [ -f build_variants/stamps_mptc.so ]; then
+  WBC_HIP_LIB=build_variants/stamps_mptc.so python3 tools/stamp_hex.py 4096 --json $out/stamps_mptc.json > $out/stamps_mptc.txt 2>&1
+  WBC_HIP_LIB=build_variants/stamps_mptc.so python3 tools/lab/r05/tail_repeat.py 3 24 > $out/tail_repeat_mptc.txt 2>&1
+fi
+if [ -f build_variants/stamps_gi_mptc.so ]; then WBC_HIP_LIB=build_variants/stamps_gi_mptc.so python3 tools/lab/r05/who_goes_generic.py > $out/who_goes_generic.txt 2>&1; fi
 cat $out/bench.json | head -c 1500; echo; head -4 $out/kernel_stats.csv; head -3 $out/id_kernel_stats.csv; tail -12 $out/pmc.log; cat $out/all_kernels.md

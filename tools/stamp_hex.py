@@ -5,7 +5,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
 from quadruped_drake_amd import MPTCController, workloads, _lib
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else 4096
+json_out = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
 b = workloads.make_batch(3, n=n)
 ctrl = MPTCController(model=b["model"], max_batch=n, device=0); ctrl.set_variant("hex")
 up = lambda x: None if x is None else torch.tensor(x, device="cuda:0")
@@ -25,6 +26,14 @@ ph = buf[:, [3, 10, 11, 12, 13, 14, 15, 6, 4]].astype(np.int64)
 dp = np.diff(ph, axis=1)
 for i, nm in enumerate(["state", "leg", "G_b + solve", "level-1 rows (+ level-2 rows, park)", "30-row append", "J rows, z", "active set", "outputs"]):
     print("  phase %-38s median %6d  p90 %6d  max %6d cycles" % (nm, np.median(dp[:, i]), np.percentile(dp[:, i], 90), dp[:, i].max()))
+if json_out:   # median cycles per phase under the names of tools/lab/isa_mix.py
+    import json
+    cyc = {"loads issue": float(np.median(d[:, 0])), "mask/mu + lds writes": float(np.median(d[:, 1])), "barrier": float(np.median(d[:, 2])),
+           "stats tail": float(np.median(d[:, 4]))}
+    for i, nm in enumerate(["state", "leg", "G_b + solve", "rows", "append", "J rows", "active set (all paths)", "outputs"]):
+        cyc[nm] = float(np.median(dp[:, i]))
+    cyc["_active_set_max"] = float(dp[:, 6].max()); cyc["_tick_median"] = float(np.median(d[:, 3])); cyc["_n"] = n
+    json.dump(cyc, open(json_out, "w"), indent=1)
 tot = t[:, 5] - t[:, 0]
 print("wave lifetime first->last stamp: p10 %d p50 %d p90 %d p99 %d max %d cycles" % tuple(np.percentile(tot, [10, 50, 90, 99, 100])))
 print("first stamp spread across blocks (launch skew): p10 %d p50 %d p90 %d max %d cycles" % tuple(np.percentile(t[:, 0] - t[:, 0].min(), [10, 50, 90, 100])))
