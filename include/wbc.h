@@ -57,6 +57,7 @@ extern "C" {
 #define WBC_NTARGET 54
 #define WBC_NU 12
 #define WBC_NMETRIC 4
+#define WBC_MAX_LD 8388608 /* largest leading dimension (and batch) of one call: 2^23 instances (7 GB of tick I/O); wbc_create / wbc_step reject more */
 
 /* wbc_create flags */
 #define WBC_DEVICE_PTRS 0u /* wbc_step receives device pointers (default) */

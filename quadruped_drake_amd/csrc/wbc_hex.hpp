@@ -1489,9 +1489,12 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     z = zacc;
     // lane (0, 3) owns no row of J: its row slots carry y = Q'b (the right-hand-side column after the append) through the active
     // set's reflections, for the evaluation of z after a drop (hex_gi)
+    // (only a robot with three or four feet down is ever evaluated that way -- `deep` in hex_gi -- so a wavefront of trotting robots skips the copy)
 #ifndef WBC_NO_DROP_REFINE
+    if (qo.wave_any(((mask & 1u) + ((mask >> 1) & 1u) + ((mask >> 2) & 1u) + ((mask >> 3) & 1u)) >= 3u)) {
 #pragma unroll
-    for (int c = 0; c < NV; c++) Jr[c] = (h == 3) ? Rcol[c] : Jr[c];
+      for (int c = 0; c < NV; c++) Jr[c] = (h == 3) ? Rcol[c] : Jr[c];
+    }
 #endif
   }
   WBC_STAMP(15);

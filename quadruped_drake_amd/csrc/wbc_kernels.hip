@@ -386,6 +386,30 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* __restric
   for (int j = 0; j < MPER; j++) t[j] = msrc[min(j * HEX_BLOCK + (int)threadIdx.x, MODEL_PAD_WORDS - 1)];
   {
     const int r0 = eb * HROBOTS;
+#if WBC_HEX_BLOCK == 64 && !defined(WBC_OLD_PROLOGUE)
+    // Word j * 64 + t of the staged block is row 16 j + (t >> 2) of robot slot t & 3: the slot (hence the robot) is a per-lane constant and the row of
+    // load j is 16 j + tr, so which array a load reads is known at compile time except for two of the six (rows 16 - 31: q | v, rows 32 - 47: v | targets).
+    // Offsets are 32-bit (wbc_step rejects ld > WBC_MAX_LD = 2^23, so 54 rows x ld x 8 bytes stay below 4 GB): one multiply-add per address instead of the
+    // two 64-bit multiply-adds, the selects between three base pointers and the 64-bit additions of the generic form (192 -> ~120 instructions before the
+    // last load is issued; stamps: profiles/r05/prologue.md).
+    static_assert(NIN == 91 && HROBOTS == 4 && PER_LANE == 6, "prologue specialised to 91 rows x 4 robots per wavefront");
+    const unsigned tr = threadIdx.x >> 2;
+    const unsigned rob = (unsigned)min(r0 + (int)(threadIdx.x & 3), n - 1), uld = (unsigned)ld;
+    tmp[0] = q[tr * uld + rob];
+    {
+      const bool lo = tr < 3u;                                   // rows 16 - 18: q, rows 19 - 31: v rows 0 - 12
+      const double* b1 = lo ? q : v;
+      tmp[1] = b1[(lo ? 16u + tr : tr - 3u) * uld + rob];
+    }
+    {
+      const bool lo = tr < 5u;                                   // rows 32 - 36: v rows 13 - 17, rows 37 - 47: targets rows 0 - 10
+      const double* b2 = lo ? v : tg;
+      tmp[2] = b2[(lo ? 13u + tr : tr - 5u) * uld + rob];
+    }
+    tmp[3] = tg[(11u + tr) * uld + rob];
+    tmp[4] = tg[(27u + tr) * uld + rob];
+    tmp[5] = tg[min(43u + tr, 53u) * uld + rob];                 // rows 80 - 90, the lanes beyond re-read the last row
+#else
 #pragma unroll
     for (int j = 0; j < PER_LANE; j++) {
       const int idx = min(j * HEX_BLOCK + (int)threadIdx.x, NIN * HROBOTS - 1);
@@ -394,10 +418,13 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* __restric
       const double* srow = row < 19 ? q + (size_t)row * ld : (row < 37 ? v + (size_t)(row - 19) * ld : tg + (size_t)(row - 37) * ld);
       tmp[j] = srow[rob];
     }
+#endif
   }
   WBC_STAMP(1);   // all loads issued
   const unsigned mk = mask[ii] & 0xF;
-  const double mu_in = mu ? mu[ii] : 0.0, ms_in = ms ? ms[ii] : 1.0;
+  // per-instance friction coefficient / mass scale, or the handle's mu / 1.0 read from the parameter block: one unconditional load each (the pointer
+  // is selected, not the load skipped: two taken branches and a dependent scalar load less in every tick without domain randomisation)
+  const double mu_in = *(mu ? mu + ii : &pp->mu), ms_in = *(ms ? ms + ii : &pp->one);
 #pragma unroll
   for (int j = 0; j < MPER; j++) mbuf[j * HEX_BLOCK + threadIdx.x] = t[j];
 #pragma unroll
@@ -424,7 +451,7 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* __restric
     if (live && lead && met) met[(size_t)k * ld + ii] = x;
     if (k == 1) errv = x;
   };
-  const double mui = mu ? mu_in : P.mu;
+  const double mui = mu_in;
   const double msi = ms_in;
   int iters = 0;
 #ifdef WBC_FORCE_SCRATCH   // diagnostic: give the kernel a private segment without changing its math
@@ -716,7 +743,7 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
                uint32_t flags, wbc_handle* out) {
   if (!model || !out) return misuse("wbc_create: null argument");
   if (kind < WBC_KIND_ID || kind > WBC_KIND_CLF) return misuse("wbc_create: kind must be WBC_KIND_ID, _MPTC, _PC or _CLF");
-  if (max_batch <= 0) return misuse("wbc_create: max_batch must be positive");
+  if (max_batch <= 0 || max_batch > WBC_MAX_LD) return misuse("wbc_create: max_batch must be in 1 .. WBC_MAX_LD (2^23)");
   wbc::ModelC m;
   if (wbc::model_from_flat(model->flat, &m)) return misuse("wbc_create: joint axes must be axis-aligned");
   if (!wbc::model_axes_are_xyy(&m))
@@ -863,6 +890,7 @@ static int check_step_args(wbc_handle h, int n, int ld, const void* q, const voi
   if (!h) return misuse("wbc_step: null handle");
   if (n < 0 || n > h->max_batch) return misuse("wbc_step: n out of range (0..max_batch)");
   if (n > 0 && ld < n) return misuse("wbc_step: ld must be >= n");
+  if (ld > WBC_MAX_LD) return misuse("wbc_step: ld exceeds WBC_MAX_LD (2^23 instances: the kernels address a row block with 32-bit offsets)");
   if (n > 0 && (!q || !v || !tg || !mask || !tau)) return misuse("wbc_step: q, v, targets, contact_mask and tau are required");
   return 0;
 }

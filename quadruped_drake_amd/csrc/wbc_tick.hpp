@@ -175,10 +175,12 @@ struct ParamsC {
 // (correctly rounded on the host as on the device: the same bits, ~60 instructions per tick less).
 struct ParamsX : ParamsC {
   double sq_eps, sq_w_body, sq_w_foot;
+  double one;   // 1.0: what a kernel reads in place of a per-instance mass scale that was not given (a load from here instead of a branch around the load)
 };
 inline void params_derive(const ParamsC& p, ParamsX* x) {
   static_cast<ParamsC&>(*x) = p;
   x->sq_eps = sqrt(p.eps2); x->sq_w_body = sqrt(p.w_body); x->sq_w_foot = sqrt(p.w_foot);
+  x->one = 1.0;
 }
 
 // ---------------------------------------------------------------- tiny vector helpers

@@ -87,6 +87,10 @@ def test_create_rejects_misuse_and_fails_loudly_without_gpu():
     m.q_perm[:] = list(range(12)); m.act_perm[:] = list(range(12))
     assert l.wbc_create(C.byref(m), 5, None, 8, 0, 0, C.byref(h)) < 0        # bad kind
     assert l.wbc_create(C.byref(m), 0, None, 0, 0, 0, C.byref(h)) < 0        # bad batch
+    hdr = open(os.path.join(ROOT, "include", "wbc.h")).read()
+    max_ld = int(re.search(r"#define WBC_MAX_LD (\d+)", hdr).group(1))
+    assert max_ld == 1 << 23
+    assert l.wbc_create(C.byref(m), 0, None, max_ld + 1, 0, 0, C.byref(h)) < 0 and b"WBC_MAX_LD" in l.wbc_last_error()   # 32-bit row offsets in the kernels
     m.q_perm[3] = 4
     assert l.wbc_create(C.byref(m), 0, None, 8, 0, 0, C.byref(h)) < 0        # not a permutation
     assert b"permutation" in l.wbc_last_error()

@@ -514,4 +514,7 @@ def test_sub_batch_with_leading_dimension():
     t = tau.cpu().numpy()
     assert np.array_equal(t[:, lo:lo + n], tau_full.cpu().numpy()[:, lo:lo + n])
     assert (t[:, :lo] == 0).all() and (t[:, lo + n:] == 0).all()
+    # a leading dimension beyond WBC_MAX_LD is API misuse (the kernels address a row block with 32-bit offsets), reported, not attempted
+    assert ctrl._L.wbc_step(ctrl._h, n, (1 << 23) + 1, P(q, 0), P(v, 0), P(tg, 0), P(mask, 0), None, None, P(tau, 0), None, None) < 0
+    assert b"WBC_MAX_LD" in ctrl._L.wbc_last_error()
     ctrl.close()

@@ -52,3 +52,25 @@ print("trips at which the live robots happen to agree on q at all (re-entry allo
 worst = np.argsort(-lens)[:max(1, len(lens) // 100)]
 print("the slowest 1 %% of the wavefronts (the launch's tail at N = 4096): %.1f trips, chain-capable %.1f of them, fast today %.1f" % (
     lens[worst].mean(), np.mean([first_exit_chain[i] for i in worst]), np.mean([first_exit_today[i] for i in worst])))
+# ---- re-entrant uniform trips: all live robots at the same q AND doing the same kind of step (all add / all drop) in this trip
+uni = uni_add = uni_drop = 0
+tail_uni = tail_tot = 0
+for w in range(0, n, 4):
+    s4 = seqs[w:w + 4]
+    T = max(len(s) for s in s4)
+    q = [0, 0, 0, 0]
+    wu = 0
+    for t in range(T):
+        live = [r for r in range(4) if t < len(s4[r])]
+        same_q = len({q[r] for r in live}) == 1
+        ops = {s4[r][t] for r in live}
+        if same_q and len(ops) == 1:
+            uni += 1; wu += 1
+            if ops == {1}: uni_add += 1
+            else: uni_drop += 1
+        for r in live:
+            q[r] += s4[r][t]
+    if T >= np.percentile(lens, 99):
+        tail_uni += wu; tail_tot += T
+print("re-entrant uniform trips (same q, same kind of step for every live robot): %.1f %% of the lock-step trips (adds %.1f %%, drops %.1f %%); in the slowest 1 %% of the wavefronts: %.1f %%" % (
+    100.0 * uni / tot, 100.0 * uni_add / tot, 100.0 * uni_drop / tot, 100.0 * tail_uni / max(tail_tot, 1)))
