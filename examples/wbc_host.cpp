@@ -234,13 +234,13 @@ int main(int argc, char** argv) {
     else { fprintf(stderr, "usage: wbc_host --batch FILE [--gpus N] [--steps K] [--warmup W] [--ramp-seconds S] [--repeat R]\n"); return 2; }
   }
   if (o.batch.empty() || o.steps <= 0 || o.repeat <= 0) { fprintf(stderr, "wbc_host: --batch FILE is required, steps and repeat positive\n"); return 2; }
+  Batch b;
+  std::string err;
+  if (!load_batch(o.batch.c_str(), &b, &err)) { fprintf(stderr, "wbc_host: %s\n", err.c_str()); return 1; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { fprintf(stderr, "wbc_host: no GPU visible (the hot path has no CPU fallback)\n"); return 1; }
   const int world = o.gpus > 0 ? o.gpus : ndev;
   if (world > ndev) { fprintf(stderr, "wbc_host: --gpus %d but %d visible\n", world, ndev); return 1; }
-  Batch b;
-  std::string err;
-  if (!load_batch(o.batch.c_str(), &b, &err)) { fprintf(stderr, "wbc_host: %s\n", err.c_str()); return 1; }
   if (b.n < world) { fprintf(stderr, "wbc_host: %d instances cannot be sharded over %d GPUs\n", b.n, world); return 1; }
   // one communicator per GPU, all owned by this process (ncclCommInitAll); each GPU thread drives its own
   std::vector<ncclComm_t> comms(world);

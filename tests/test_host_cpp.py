@@ -53,6 +53,29 @@ def test_host_binary_is_built_and_links_the_abi_and_rccl_only():
     assert r.returncode == 2 and "--batch" in r.stderr
 
 
+def test_host_binary_rejects_a_bad_batch_file_and_has_no_cpu_path(tmp_path):
+    """The batch file is parsed before any GPU call: a truncated / foreign file is an error message and exit code 1, and a good file without a
+    GPU ends with "no GPU visible" -- the C++ host has no CPU fallback either."""
+    from quadruped_drake_amd import workloads
+    if not os.path.exists(EXE):
+        import __graft_entry__ as g
+        g.build()
+    bad = tmp_path / "bad.bin"; bad.write_bytes(b"NOTABATCH" + bytes(64))
+    r = subprocess.run([EXE, "--batch", str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "bad batch file" in r.stderr
+    good = workloads.dump_batch(str(tmp_path / "b.bin"), workloads.make_batch(3, n=8))
+    raw = open(good, "rb").read()
+    cut = tmp_path / "cut.bin"; cut.write_bytes(raw[:len(raw) - 40])
+    r = subprocess.run([EXE, "--batch", str(cut)], capture_output=True, text=True)
+    assert r.returncode == 1 and "bad batch file" in r.stderr
+    r = subprocess.run([EXE, "--batch", str(tmp_path / "missing.bin")], capture_output=True, text=True)
+    assert r.returncode == 1 and "cannot open" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        r = subprocess.run([EXE, "--batch", good], capture_output=True, text=True)
+        assert r.returncode == 1 and "no GPU visible" in r.stderr
+
+
 def _last_json(text):
     lines = [l for l in text.splitlines() if l.startswith("{")]
     assert lines, text[-2000:]
