@@ -433,13 +433,13 @@ def run_rank(a):
     dt_cold = time.perf_counter() - t0c
     # clock ramp: the GPU raises its clock over the first ~1 s of sustained load (measured: 29.4 -> 26.7 us per launch,
     # profiles/r02/tail_experiment.md); steady state is what a control loop sees, so the ramp is not part of the W + K steps
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < a.ramp_seconds:
-        ctrl.time_steps(100, q, v, tg, mask, mu, ms, out=out)
+    wstats.all_gather_stats(ctrl.stats(), device=cdev)            # warm the statistics exchange (RCCL channel set-up) BEFORE the ramp: nothing but the W warm-up
+    t_ramp = time.perf_counter()                                  # steps, an asynchronous statistics reset and the bracket's own waits lies between the ramp and t0 -- the
+    while time.perf_counter() - t_ramp < a.ramp_seconds:          # GPU's clock governor answers a few hundred idle microseconds after a burst with a lower clock
+        ctrl.time_steps(100, q, v, tg, mask, mu, ms, out=out)     # (tools/lab/r05/k20_probe.py: 23.2 -> 25.5 us per launch), which a K = 20 region never recovers from
     for _ in range(a.warmup):
         bound.step()
-    wstats.all_gather_stats(ctrl.stats(), device=cdev)            # warm the statistics exchange (RCCL channel set-up) as well
-    ctrl.stats(reset=True)
+    ctrl.stats_reset()                                            # queued behind the warm-up steps, not waited for: the statistics cover exactly the K timed steps
     sync(); barrier(); sync()
     t0 = time.perf_counter()
     # exactly K steps; HIP events on the launch stream bracket the same K launches

@@ -238,6 +238,11 @@ class BatchedController:
             _lib.check(self._L.wbc_stats_reset(self._h))
         return d
 
+    def stats_reset(self):
+        """Zero the device-side statistics, asynchronously on the handle's stream (wbc_stats_reset): no wait, unlike stats(reset=True)."""
+        self._bind_stream()
+        _lib.check(self._L.wbc_stats_reset(self._h))
+
     # -- closed-loop rollouts (SURVEY 8f row 4) ---------------------------------------------------
     def set_vdot_output(self, vdot, n=None):
         """CUDA float64 [18, N] tensor that every step() fills with the QP's generalized accelerations (None: off)."""
