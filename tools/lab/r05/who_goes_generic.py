@@ -9,7 +9,8 @@ import host_tick as ht
 from oracle import oracle_py as orc
 from quadruped_drake_amd import MPTCController, workloads, _lib
 n = 4096
-b = workloads.make_batch(3, n=n)
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else None
+b = workloads.make_batch(3, n=n, seed=seed)
 ctrl = MPTCController(model=b["model"], max_batch=n, device=0)
 up = lambda x: None if x is None else torch.tensor(x, device="cuda:0")
 args = [up(b[k]) for k in ("q", "v", "targets", "mask", "mu", "mass_scale")]
