@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line.
 """
 import argparse
 import hashlib
+import gc
 import json
 import os
 import socket
@@ -431,23 +432,50 @@ def run_rank(a):
     ms_cold = bound.time_steps_result()
     sync(); barrier(); sync()
     dt_cold = time.perf_counter() - t0c
+
+    def rollout(steps):
+        """K launches + the two events queued, the end-of-rollout statistics (reduction kernel, the ONE host wait, the gather: RCCL when world > 1),
+        the closing bracket.  Host time stamps (rank-local): start, launches queued, statistics here, gathered, bracket closed.  Nothing else is inside:
+        the events are read and the dictionaries built after the bracket has closed."""
+        ts = [time.perf_counter()]
+        bound.time_steps(steps, wait=False)        # exactly `steps` launches; HIP events on the launch stream bracket the same launches
+        ts.append(time.perf_counter())
+        local_st = ctrl.stats()
+        ts.append(time.perf_counter())
+        red = wstats.all_gather_stats(local_st, device=cdev) if use_pg else None
+        ts.append(time.perf_counter())
+        sync(); barrier(); sync()
+        ts.append(time.perf_counter())
+        ms_launch = bound.time_steps_result()      # the events completed before the statistics did: no wait here
+        if red is None:
+            red = (dict(local_st), [dict(local_st)], 1)
+        return ts, ms_launch, red
+
+    # A REHEARSAL of the timed region -- the same calls in the same order, W steps -- BEFORE the clock ramp, so that the region itself meets warm code
+    # paths (interpreter, ctypes thunks, the runtime's wait path) and a connected statistics exchange (RCCL channel set-up): with the driver's K = 20 a
+    # region entered for the first time spent 67 - 78 us outside its launches, a rehearsed one 35 - 40 (`region_us` below says where).  Before the
+    # ramp, not after it: the GPU's clock governor answers a few hundred idle microseconds after a burst with a lower clock (tools/lab/r05/k20_probe.py:
+    # 23.2 -> 25.5 us per launch), which a K = 20 region never recovers from; between the ramp and t0 lie only the W warm-up steps, an asynchronous
+    # statistics reset and the bracket's own waits.
+    rollout(max(a.warmup, 1))
     # clock ramp: the GPU raises its clock over the first ~1 s of sustained load (measured: 29.4 -> 26.7 us per launch,
     # profiles/r02/tail_experiment.md); steady state is what a control loop sees, so the ramp is not part of the W + K steps
-    wstats.all_gather_stats(ctrl.stats(), device=cdev)            # warm the statistics exchange (RCCL channel set-up) BEFORE the ramp: nothing but the W warm-up
-    t_ramp = time.perf_counter()                                  # steps, an asynchronous statistics reset and the bracket's own waits lies between the ramp and t0 -- the
-    while time.perf_counter() - t_ramp < a.ramp_seconds:          # GPU's clock governor answers a few hundred idle microseconds after a burst with a lower clock
-        ctrl.time_steps(100, q, v, tg, mask, mu, ms, out=out)     # (tools/lab/r05/k20_probe.py: 23.2 -> 25.5 us per launch), which a K = 20 region never recovers from
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < a.ramp_seconds:
+        bound.time_steps(100)
     for _ in range(a.warmup):
         bound.step()
-    ctrl.stats_reset()                                            # queued behind the warm-up steps, not waited for: the statistics cover exactly the K timed steps
+    ctrl.stats_reset()                                            # queued, not waited for: the statistics cover exactly the K timed steps
+    gc_was = gc.isenabled()
+    gc.disable()                                                  # no collector pause inside a 0.5 ms region (what timeit does)
     sync(); barrier(); sync()
-    t0 = time.perf_counter()
-    # exactly K steps; HIP events on the launch stream bracket the same K launches
-    bound.time_steps(a.steps, wait=False)        # K launches + the two events queued; ONE host wait follows, in stats()
-    st, per_rank, seen = wstats.all_gather_stats(ctrl.stats(), device=cdev)   # end-of-rollout statistics (RCCL when world > 1)
-    ms_per_launch = bound.time_steps_result()    # the events completed before the statistics did: no second wait
-    sync(); barrier(); sync()
-    dt = time.perf_counter() - t0
+    ts, ms_per_launch, (st, per_rank, seen) = rollout(a.steps)
+    if gc_was:
+        gc.enable()
+    t0 = ts[0]
+    dt = ts[4] - t0
+    # where this rank's region went (host clock, microseconds): queueing the K launches | the statistics reduction and the ONE wait | the gather | the closing bracket
+    region_us = [round((ts[i + 1] - ts[i]) * 1e6, 1) for i in range(4)]
     per_rank_kernel_ms = [ms_per_launch]
     # parity on EVERY rank: 64 instances spread over this rank's shard against the oracle (the checker), status of the whole shard
     par_rel, par_bad = 0.0, float((out[2] != 0).sum())        # par_bad: the DEVICE's count over the whole shard, nothing else
@@ -529,6 +557,9 @@ def run_rank(a):
             # which weigh 1.5 us per step at the driver's K = 20 and 0.15 at K = 200): instances / slowest rank's HIP-event launch time
             "value_kernel_only": n_total / (ms_per_launch * 1e-3),
             "value_cold": n_total * a.steps / dt_cold, "kernel_ms_cold": ms_cold,
+            "region_us": {"queue_K_launches": region_us[0], "statistics_reduce_and_the_one_wait": region_us[1], "gather": region_us[2],
+                          "closing_bracket": region_us[3], "total": round(dt * 1e6, 1), "device_time_of_the_K_launches": round(ms_per_launch * 1e3 * a.steps, 1),
+                          "note": "rank 0's host clock inside the timed region"},
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic", "backend": a.backend, "ramp_seconds": a.ramp_seconds,

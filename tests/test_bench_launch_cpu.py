@@ -16,7 +16,7 @@ def _run(args, env_extra=None, timeout=300):
 
 
 def test_self_launch_world2_gloo_dry_run():
-    r = _run(["--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--per-gpu", "64"])
+    r = _run(["--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "3", "--warmup", "1", "--per-gpu", "64"])   # --dry-run: the same on a box WITH a GPU
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                   # rank 0 prints ONE JSON line, relayed by the parent
@@ -36,7 +36,7 @@ def test_self_launch_propagates_a_failing_rank():
 
 def test_one_rank_process_group_gloo_dry_run():
     """--force-pg: ONE rank still initialises the group and sends its statistics through the collective (the RCCL path's CPU twin)."""
-    r = _run(["--gpus", "1", "--force-pg", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--per-gpu", "64"])
+    r = _run(["--gpus", "1", "--force-pg", "--backend", "gloo", "--dry-run", "--steps", "3", "--warmup", "1", "--per-gpu", "64"])
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["dry_run"] is True and d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["per_rank_ticks"] == [64.0 * 3]

@@ -5,6 +5,7 @@ choosing the row whose pair-mate is a leaves b's multiplier reduced by the new r
 Tie-break rules on the dumped problems (numpy Goldfarb-Idnani, most violated row, apex rule on):
   noise   rounding decides (today)                 mate-small   complete the pair whose active mate has the SMALLER multiplier
   mate-big  ... the LARGER multiplier              first        lowest row index
+  exact     the candidate whose step is not blocked, if either (what a swap after the blocked trip would achieve)
     python tools/lab/r05/apex_tie.py /tmp/gi_cfg2_id_4096.npz [n]"""
 import os
 import sys
@@ -46,6 +47,17 @@ def gi(D, y0, elig, tol_abs, rule, rng):
                         pref = min(rest, key=lambda h: u[mate[h]])
                     elif rule == "mate-big":
                         pref = max(rest, key=lambda h: u[mate[h]])
+                    elif rule == "exact":
+                        # the candidate whose step is FULL, if either is (same z and t2 for both, r differs by e_b - e_a: apex_rule.md section 6)
+                        def full(h):
+                            r = np.linalg.lstsq(D[A].T, D[h], rcond=None)[0]
+                            zd = D[h] - D[A].T @ r; zz = zd @ zd
+                            if zz <= 1e-22 * (D[h] @ D[h]):
+                                return False
+                            t2 = -(D[h] @ y) / zz
+                            return all(not (r[j] > 0 and lam[j] / r[j] < t2) for j in range(len(A)))
+                        ok = [h for h in rest if full(h)]
+                        pref = ok[0] if ok else min(rest)
                     else:
                         pref = min(rest)
                     for h in rest:
@@ -87,7 +99,7 @@ if __name__ == "__main__":
     elig = np.repeat(ct, 4, axis=1)
     n = min(n, D.shape[0])
     ref = None
-    for rule in ("noise", "mate-small", "mate-big", "first"):
+    for rule in ("noise", "mate-small", "mate-big", "first", "exact"):
         rng = np.random.default_rng(0)
         v = []; sols = []
         for i in range(n):
