@@ -200,7 +200,7 @@ WBC_HD int hex_pick_index(double k) {
 // joint in a second constraint slot (id 32 + lane): unit normal Tn of the torque-map row, normalised torque
 // yt = Tn.z + t0n tracked like s_h, bound bt = tau_max / |T_row| (< 0: slot not eligible).  Only one side of a
 // pair can be violated or active at a time; the side is a sign (sig) applied to the slot's image.
-template <class Q, bool PC, int NV = NZ, bool TB = false, bool GAIN = false>
+template <class Q, bool PC, int NV = NZ, bool TB = false, bool GAIN = false, bool HYB = false>
 WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, double inv_s, int* iters_out,
                   double vrow_own = 0.0, double vc = 0.0, double pc_inv = 0.0, const double* Tn = nullptr,
                   double t0n = 0.0, double bt = -1.0, bool deep = true) {
@@ -288,7 +288,22 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #ifndef WBC_QF_ID
 #define WBC_QF_ID 8
 #endif
-  constexpr int QF = (!TB && NV == NZ) ? (GAIN ? 8 : WBC_QF_ID) : 0;   // ID stands add up to 8-12 rows before the first drop; PC: see pcv below
+#ifndef WBC_CLF_FAST
+#define WBC_CLF_FAST 0   // CLF (13 slots) through the fast path too: built, bit-identical, measured -1 ... +3 % (profiles/r05/hybrid_pick.md): off
+#endif
+#ifndef WBC_HYBRID_PICK
+#define WBC_HYBRID_PICK 1   // dense-row laws (PC, CLF): pick rule by contact count (hex_gi)
+#endif
+  constexpr int QF = (!TB && (NV == NZ || WBC_CLF_FAST)) ? (GAIN ? 8 : WBC_QF_ID) : 0;   // ID stands add up to 8-12 rows before the first drop; PC: see pcv below
+  // Which inactive row to add -- Goldfarb-Idnani may take any violated one.  Greatest dual gain s^2 / |free part|^2 (GAIN) needs fewer trips where few rows
+  // end up active (one or two feet down: -12 ... -30 % trips), the most violated row needs fewer on saturated stands (four feet: -4 ... -7 % trips and no
+  // gain arithmetic: -15 % launch time); three feet: a wash (host emulation by contact count, profiles/r05/hybrid_pick.md).  HYB: the rule is chosen PER
+  // ROBOT by its contact count (`deep` = three or four feet down) and a wavefront of deep robots skips the gain arithmetic.  The dense-row laws (PC, CLF)
+  // are built that way; the friction-only laws keep their compile-time rule (MPTC: gain, ID: most violated) -- the two votes and the per-pick branch
+  // measured +1.5 % on the headline launch and +2 % on the ID stand, the two BASELINE lines, for -2 ... -3 % on their off-design batches.
+  const bool use_gain = HYB ? (GAIN && !deep) : GAIN;                          // per robot
+  const bool wave_gain_any = HYB ? (GAIN && qo.wave_any(!deep)) : GAIN;        // wave-uniform: somebody needs the gains
+  const bool wave_gain_all = HYB ? (GAIN && qo.wave_all(!deep)) : GAIN;        // wave-uniform: every candidate of the wavefront is a violated row
   bool generic = true;   // wave-uniform: the generic loop still has work to do
   // What an abandoned fast trip has already worked out -- pick, the picked row's image, the step's dots, the blocking ratio, the norm --
   // is the front half of a generic trip, evaluated by the same expressions: the first generic trip takes it over instead of
@@ -307,10 +322,16 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       {
         double key = HEX_NONE;
         if (!done && ct && !act_h && !(APEX && nleg == 3)) {
-          if (GAIN) {
+          if (GAIN && wave_gain_any) {
             double dd2 = 0.0;
-            static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; dd2 = fmad(Dh[k], Dh[k], dd2); });
-            if (sh_ < -tol) key = pick_pack((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
+            static_for<NV - qc>([&](auto KK) { constexpr int k = qc + KK; dd2 = fmad(Dh[k], Dh[k], dd2); });
+            if constexpr (HYB) {
+              const double gk = (dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290;
+              if (!use_gain) key = pick_pack(sh_, h);
+              else if (sh_ < -tol) key = pick_pack(gk, h);
+            } else {
+              if (sh_ < -tol) key = pick_pack((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
+            }
           } else {
             key = pick_pack(sh_, h);
           }
@@ -325,18 +346,18 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       if (qo.wave_all(done || (pf < 0 && !pcv))) { done = true; stop = true; generic = false; return; }
       // ONE round trip: the picked row's image, value and norm from its lane (own lane when there is no candidate)
       const int pl = (pf >= 0) ? pf : h;
-      double d[NZ];
+      double d[NV];
 #pragma unroll
-      for (int k = 0; k < NZ; k++) d[k] = qo.bcast16d(Dh[k], pl);
+      for (int k = 0; k < NV; k++) d[k] = qo.bcast16d(Dh[k], pl);
       const double spx = qo.bcast16d(sh_, pl), dnx = qo.bcast16d(dnh, pl);
       // the dense row wins the pick when it is the most violated one (generic loop: spc < sp)
       const bool pcpick = pcv && !(pf >= 0 && !(spc < spx));
       if (!(pf >= 0 && spx < -tol) && !pcpick) done = true;        // nothing (left) to repair on this robot
       // (with the gain pick only violated rows are candidates: a robot with a candidate stays live, the test above was the exit)
-      if (!GAIN && qo.wave_all(done)) { stop = true; generic = false; return; }
+      if (!wave_gain_all && qo.wave_all(done)) { stop = true; generic = false; return; }
       double d2n = 0.0, zd = 0.0, sd = 0.0, r_h = 0.0;
-      static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; d2n = fmad(d[k], d[k], d2n); });
-      static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; zd = fmad(Jr[k], d[k], zd); sd = fmad(Dh[k], d[k], sd); });
+      static_for<NV - qc>([&](auto KK) { constexpr int k = qc + KK; d2n = fmad(d[k], d[k], d2n); });
+      static_for<NV - qc>([&](auto KK) { constexpr int k = qc + KK; zd = fmad(Jr[k], d[k], zd); sd = fmad(Dh[k], d[k], sd); });
       static_for<qc>([&](auto KK) { r_h = fmad(Wr[KK], d[KK], r_h); });
       r_h = act_h ? r_h : 0.0;
       double t1 = INF;
@@ -360,7 +381,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
           ho_p = pf; ho_sp = spx; ho_dn = dnx; ho_d2n = d2n; ho_zd = zd; ho_sd = sd; ho_r = r_h;
           ho_t1 = t1; ho_hd = have_t1 ? hex_key_index(t1) : -1;
 #pragma unroll
-          for (int k = 0; k < NZ; k++) ho_d[k] = d[k];
+          for (int k = 0; k < NV; k++) ho_d[k] = d[k];
         }
 #endif
         return;
@@ -380,14 +401,14 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         const double w = fmad(-alpha, Jr[qc], zd) * beta, wd = fmad(-alpha, Dh[qc], sd) * beta;   // x . v = x . d[qc:] - alpha x_qc
         Jr[qc] = fmad(-w, vq, Jr[qc]);
         Dh[qc] = fmad(-wd, vq, Dh[qc]);
-        static_for<NZ - qc - 1>([&](auto KK) { constexpr int k = qc + 1 + KK; Jr[k] = fmad(-w, d[k], Jr[k]); Dh[k] = fmad(-wd, d[k], Dh[k]); });
+        static_for<NV - qc - 1>([&](auto KK) { constexpr int k = qc + 1 + KK; Jr[k] = fmad(-w, d[k], Jr[k]); Dh[k] = fmad(-wd, d[k], Dh[k]); });
         if (PC) {
           double sdpc = 0.0;
-          static_for<NZ - qc>([&](auto KK) { constexpr int k = qc + KK; sdpc = fmad(Dpc[k], d[k], sdpc); });
+          static_for<NV - qc>([&](auto KK) { constexpr int k = qc + KK; sdpc = fmad(Dpc[k], d[k], sdpc); });
           spc = fmad(t2, sdpc, spc);
           const double wp = fmad(-alpha, Dpc[qc], sdpc) * beta;
           Dpc[qc] = fmad(-wp, vq, Dpc[qc]);
-          static_for<NZ - qc - 1>([&](auto KK) { constexpr int k = qc + 1 + KK; Dpc[k] = fmad(-wp, d[k], Dpc[k]); });
+          static_for<NV - qc - 1>([&](auto KK) { constexpr int k = qc + 1 + KK; Dpc[k] = fmad(-wp, d[k], Dpc[k]); });
         }
         const bool mine = (h == pf);
         Wr[qc] = mine ? ia : -r_h * ia;
@@ -428,7 +449,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         // most violated inactive row: argmin of the tracked values (friction slot: index h, torque slot: 16 + h)
         {
           double key = HEX_NONE;
-          if (GAIN) {
+          if (GAIN && wave_gain_any) {
             // greatest dual gain s^2 / |D_h[q:]|^2 instead of the most violated row: fewer iterations for the worst
             // robots of a trot batch (max 7 -> 6, rows needing >= 5: 88 -> 32 of 4096), more for the 4-contact ID stand
             double dd2 = 0.0;
@@ -436,8 +457,16 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
             for (int k = 0; k < NV; k++) dd2 = fmad(mk[k] * Dh[k], Dh[k], dd2);
             // a violated row whose image has no free part (linearly dependent on the active ones) must still be
             // picked -- the dependent-step logic below resolves or reports it -- so it gets the largest finite gain
-            if (ct && !act_h && !(APEX && nleg == 3) && sh_ < -tol)
-              key = pick_pack((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
+            if constexpr (HYB) {
+              const double gk = (dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290;
+              if (ct && !act_h && !(APEX && nleg == 3)) {
+                if (!use_gain) key = pick_pack(sh_, h);
+                else if (sh_ < -tol) key = pick_pack(gk, h);
+              }
+            } else {
+              if (ct && !act_h && !(APEX && nleg == 3) && sh_ < -tol)
+                key = pick_pack((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
+            }
           } else {
             if (ct && !act_h && !(APEX && nleg == 3)) key = pick_pack(sh_, h);
           }
@@ -1508,10 +1537,10 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     (void)s;
     int st;
     if (KIND == KIND_PC) {
-      st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu * rs, rs, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt, deep);
+      st = hex_gi<Q, true, NV, TB, WBC_HYBRID_PICK && !TB, true>(qo, h, ct, Jr, z, mu * rs, rs, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt, deep);
     } else if (KIND == KIND_CLF) {
       // the CLF row  g . [z; delta] - ub <= 0  is the dense row of the active set (index 16), like PC's Vdot row
-      st = hex_gi<Q, true, NV, TB>(qo, h, ct, Jr, z, mu * rs, rs, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt, deep);
+      st = hex_gi<Q, true, NV, TB, WBC_HYBRID_PICK && !TB, true>(qo, h, ct, Jr, z, mu * rs, rs, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt, deep);
     } else {
 #ifndef WBC_GAIN_ID
 #define WBC_GAIN_ID 0

@@ -356,3 +356,44 @@ def test_apex_rule_and_deterministic_pick_on_host(tmp_path):
     tau_new, _, st, it_new = ht.run("mptc", orc.load_model_json(bt["model"])["flat"], bt["q"], bt["v"], bt["targets"], bt["mask"], hexv=True)
     tau_old, it_old = run_old("mptc", bt)
     assert (st == 0).all() and rel_err(tau_new, tau_old).max() < 1e-6 and it_new.mean() <= it_old.mean() + 0.02
+
+
+def test_pick_rule_by_contact_count_on_the_dense_row_laws(tmp_path):
+    """Round 5 (csrc/wbc_hex.hpp: hex_gi, HYB; profiles/r05/hybrid_pick.md).  PC and CLF choose the row to add per robot: greatest dual gain with one
+    or two feet down, the most violated row with three or four.  Against a build without it (-DWBC_HYBRID_PICK=0: most violated everywhere): the same
+    solutions, fewer trips and fewer drops on the trot batch, bit-identical outputs on the 4-contact stands (every robot there is `deep`)."""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dp = C.POINTER(C.c_double)
+    so = str(tmp_path / "libhost_nohybrid.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", "-DWBC_HYBRID_PICK=0",
+                           "-o", so, os.path.join(root, "tools", "host_tick.cpp")])
+    old = C.CDLL(so)
+
+    def run_old(kind, b):
+        n = b["q"].shape[1]
+        t = orc.load_model_json(b["model"])
+        q, v, tg = (np.ascontiguousarray(b[x]) for x in ("q", "v", "targets"))
+        flat = np.ascontiguousarray(t["flat"], dtype=np.float64)
+        tau = np.zeros((12, n)); met = np.zeros((4, n)); st = np.zeros(n, np.int32); it = np.zeros(n, np.int32)
+        rc = old.host_hex_batch({"pc": 2, "clf": 3}[kind], flat.ctypes.data_as(dp), None, None, None, n, n, q.ctypes.data_as(dp),
+                                v.ctypes.data_as(dp), tg.ctypes.data_as(dp), b["mask"].ctypes.data_as(C.POINTER(C.c_ubyte)), None, None,
+                                tau.ctypes.data_as(dp), met.ctypes.data_as(dp), st.ctypes.data_as(C.POINTER(C.c_int)),
+                                it.ctypes.data_as(C.POINTER(C.c_int)))
+        assert rc == 0
+        return tau, st, it
+
+    for kind in ("pc", "clf"):
+        bt = workloads.make_batch(3, n=256)
+        tau_new, _, st, it_new = ht.run(kind, orc.load_model_json(bt["model"])["flat"], bt["q"], bt["v"], bt["targets"], bt["mask"], hexv=True)
+        tau_old, st_old, it_old = run_old(kind, bt)
+        assert (st == 0).all() and (st_old == 0).all()
+        assert rel_err(tau_new, tau_old).max() < 1e-7                       # the same QP solution by another walk
+        assert it_new.mean() < it_old.mean() - 0.03 and it_new.max() <= it_old.max()
+        assert it_new.reshape(-1, 4).max(1).mean() < it_old.reshape(-1, 4).max(1).mean()      # lock step of four: what the device pays
+        bs = workloads.make_batch(2, n=64)
+        tau_new, _, st, it_new = ht.run(kind, orc.load_model_json(bs["model"])["flat"], bs["q"], bs["v"], bs["targets"], bs["mask"], hexv=True)
+        tau_old, st_old, it_old = run_old(kind, bs)
+        assert np.array_equal(tau_new, tau_old) and np.array_equal(it_new, it_old) and np.array_equal(st, st_old)
