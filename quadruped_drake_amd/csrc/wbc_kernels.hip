@@ -135,7 +135,13 @@ __device__ __forceinline__ double wave_max(double x) {
 
 constexpr int NIN = 19 + 18 + 54;    // input rows per robot (q, v, targets)
 constexpr int MODEL_PAD_WORDS = 320;  // ModelC padded to 2.5 KB (multiple of 64 8-byte words)
-constexpr int MODEL_REPLICAS = 256;   // per-block replicas of the model table in HBM
+// Replicas of the 2.5 KB model table in HBM, read by workgroup b % MODEL_REPLICAS: ONE copy is a hot line for a thousand wavefronts that start together (round 1: +18 us in the
+// first phase), one per workgroup is 640 KB of HBM reads per launch for 3 MB of inputs.  32 = four per XCD under the round-robin dispatch: same launch time as 256 (22.6 us; N = 32768
+// 150.6 against 151.8), HBM bytes per launch 5.33 -> 4.79 MB (profiles/r05/model_replicas.md).
+#ifndef WBC_MODEL_REPLICAS
+#define WBC_MODEL_REPLICAS 32
+#endif
+constexpr int MODEL_REPLICAS = WBC_MODEL_REPLICAS;
 static_assert(sizeof(wbc::ModelC) <= MODEL_PAD_WORDS * 8 && MODEL_PAD_WORDS % 64 == 0, "model padding");
 
 // ---------------------------------------------------------------- v4: 16 lanes (one DPP row) per robot
