@@ -115,3 +115,10 @@ def test_bench_one_gpu_through_the_process_group_branch():
         ent = json.load(f)["mptc_cfg3_n4096_hex"]
     same_build = ent.get("kernel_src_sha16") == bench.kernel_src_sha16()
     assert (d["roofline"]["traffic"] == ent["bytes_per_launch"]) if same_build else (d["roofline"]["traffic"] is None)
+    # the timed region's own accounting (round 5): four parts by the host clock, the device time of the K launches inside the total, the line's
+    # ms_per_step = total / K, the kernel-only rate from the HIP events
+    reg = d["region_us"]
+    parts = reg["queue_K_launches"] + reg["statistics_reduce_and_the_one_wait"] + reg["gather"] + reg["closing_bracket"]
+    assert abs(parts - reg["total"]) < 1.0 and reg["device_time_of_the_K_launches"] < reg["total"]
+    assert abs(d["ms_per_step"] * 1e3 * 10 - reg["total"]) < 1.0
+    assert abs(d["value_kernel_only"] - 4096.0 / (d["roofline"]["kernel_ms"] * 1e-3)) < 1e-6 * d["value_kernel_only"] and d["value_kernel_only"] > d["value"]
