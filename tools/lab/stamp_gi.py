@@ -5,14 +5,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 os.environ["WBC_HIP_LIB"] = os.path.abspath(sys.argv[1])
 import torch
-from quadruped_drake_amd import IDController, MPTCController, workloads, _lib
+from quadruped_drake_amd import IDController, MPTCController, PCController, CLFController, workloads, _lib
 kind, cfg = sys.argv[2].split(":"); cfg = int(cfg); n = 4096
 src = int(sys.argv[3]) if len(sys.argv) > 3 else None
 b = workloads.make_batch(cfg, n=n)
 if src is not None:
     for k in ("q", "v", "targets"): b[k][:] = b[k][:, src:src + 1]
     b["mask"][:] = b["mask"][src]
-ctrl = {"id": IDController, "mptc": MPTCController}[kind](model=b["model"], max_batch=n, device=0)
+ctrl = {"id": IDController, "mptc": MPTCController, "pc": PCController, "clf": CLFController}[kind](model=b["model"], max_batch=n, device=0)
 up = lambda x: None if x is None else torch.tensor(x, device="cuda:0")
 args = [up(b[k]) for k in ("q", "v", "targets", "mask", "mu", "mass_scale")]
 for _ in range(200): ctrl.step(*args)
@@ -29,3 +29,4 @@ print("iters/tick %.2f; active-set phase (stamp 15 -> 6 n/a); generic sections, 
 for i, nm in enumerate(["pick", "fetch", "step", "drop vector", "reflection"]):
     print("  %-12s mean %8.0f  max %8.0f" % (nm, acc[:, i].mean(), acc[:, i].max()))
 print("  total        mean %8.0f  max %8.0f  (%.2f us at 2.4 GHz)" % (tot.mean(), tot.max(), tot.max() / 2400))
+print("  slot 15 (generic trips counted by the build, if it counts them): mean %.2f max %d" % (buf[:, 15].mean(), buf[:, 15].max()))

@@ -4,11 +4,13 @@ import ctypes as C, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
-from quadruped_drake_amd import MPTCController, workloads, _lib
+from quadruped_drake_amd import IDController, MPTCController, PCController, CLFController, workloads, _lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else 4096
 json_out = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
-b = workloads.make_batch(3, n=n)
-ctrl = MPTCController(model=b["model"], max_batch=n, device=0); ctrl.set_variant("hex")
+kind = sys.argv[sys.argv.index("--kind") + 1] if "--kind" in sys.argv else "mptc"      # the stamp build must hold that law (-DWBC_DEV_ONLY=<kind id>)
+cfg = int(sys.argv[sys.argv.index("--config") + 1]) if "--config" in sys.argv else 3
+b = workloads.make_batch(cfg, n=n)
+ctrl = {"id": IDController, "mptc": MPTCController, "pc": PCController, "clf": CLFController}[kind](model=b["model"], max_batch=n, device=0); ctrl.set_variant("hex")
 up = lambda x: None if x is None else torch.tensor(x, device="cuda:0")
 args = [up(b[k]) for k in ("q", "v", "targets", "mask", "mu", "mass_scale")]
 for _ in range(5): ctrl.step(*args)
