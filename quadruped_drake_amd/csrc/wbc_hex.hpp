@@ -162,6 +162,9 @@ WBC_HD int hex_key_index(double k) {
 // device and from build to build, and one of the two choices ends in a blocked step: a drop and a re-add, on the device two generic trips for
 // the whole wavefront (the slowest wavefront of the headline launch was such a robot; profiles/r05/apex_rule.md).  The pick only needs
 // SOME violated row, the exact value of the picked row is fetched from its lane; the blocking-ratio keys (hex_pack_key) stay at 2^-47.
+#ifndef WBC_LAZY_DENSE
+#define WBC_LAZY_DENSE 1   // dense-row laws: the dense row's image is built when it is needed, not reflected every trip (hex_gi)
+#endif
 #ifndef WBC_PICK_BITS
 #define WBC_PICK_BITS 24
 #endif
@@ -225,10 +228,25 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #endif
   double Dpc[NV], spc = 0.0, dnpc = 0.0, u_pc = 0.0;
   bool act_pc = false;
-  if (PC) {
+  // The dense row (PC: Vdot <= 0, CLF: its decrease condition) is inactive on most robots and most ticks.  LAZY: instead of reflecting its image D_pc through
+  // every trip (and building it up front: thirteen 16-lane sums), its VALUE is taken fresh from the current z at every pick (one 16-lane sum) and its image is
+  // built from the current rows of J only in a trip that adds it (or, for the evaluation after a drop, while it is active): profiles/r05/lazy_dense.md.
+  constexpr bool LAZY = PC && (NV != NZ) && (WBC_LAZY_DENSE != 0);   // CLF (13 slots): -4 ... -5 %; PC measured no gain (its trips are mostly fast-path ones) and keeps the reflected image
+  auto dense_value = [&]() -> double { return -(qo.sum16(vrow_own * z) + vc) * pc_inv; };
+  auto dense_image = [&](double* D) -> double {
+    double n2 = 0.0;
 #pragma unroll
-    for (int k = 0; k < NV; k++) { Dpc[k] = qo.sum16(Jr[k] * npl); dnpc += Dpc[k] * Dpc[k]; }
-    spc = -(qo.sum16(vrow_own * z) + vc) * pc_inv;
+    for (int k = 0; k < NV; k++) { D[k] = qo.sum16(Jr[k] * npl); n2 += D[k] * D[k]; }
+    return n2;
+  };
+  if (PC) {
+    if constexpr (LAZY) {
+      spc = dense_value();
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV; k++) { Dpc[k] = qo.sum16(Jr[k] * npl); dnpc += Dpc[k] * Dpc[k]; }
+      spc = -(qo.sum16(vrow_own * z) + vc) * pc_inv;
+    }
   }
   double u_h = 0.0, Wr[NV], Wpc[NV];
   bool act_h = false;   // own friction row is in the active set
@@ -341,6 +359,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       }
       // PC law: the dense row (Vdot <= 0) is never added here -- a robot whose dense row is violated sends the wavefront to the
       // generic loop (rare: ~5 % of the robots); while it is inactive the fast trips only carry its image and value along
+      if constexpr (LAZY && qc > 0) { if (pc) spc = dense_value(); }
       const bool pcv = PC && pc && spc < -tol;
       // every wavefront's last trip finds nothing left to repair anywhere: leave before the crossbar round trip
       if (qo.wave_all(done || (pf < 0 && !pcv))) { done = true; stop = true; generic = false; return; }
@@ -402,7 +421,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         Jr[qc] = fmad(-w, vq, Jr[qc]);
         Dh[qc] = fmad(-wd, vq, Dh[qc]);
         static_for<NV - qc - 1>([&](auto KK) { constexpr int k = qc + 1 + KK; Jr[k] = fmad(-w, d[k], Jr[k]); Dh[k] = fmad(-wd, d[k], Dh[k]); });
-        if (PC) {
+        if (PC && !LAZY) {
           double sdpc = 0.0;
           static_for<NV - qc>([&](auto KK) { constexpr int k = qc + KK; sdpc = fmad(Dpc[k], d[k], sdpc); });
           spc = fmad(t2, sdpc, spc);
@@ -446,6 +465,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     bool all_done = false;
     if (!takeover) {
       if (!done && need_pick) {
+        if constexpr (LAZY) { if (pc && !act_pc) spc = dense_value(); }
         // most violated inactive row: argmin of the tracked values (friction slot: index h, torque slot: 16 + h)
         {
           double key = HEX_NONE;
@@ -502,7 +522,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         } else {
           up = 0.0;
           dnp = dn_x;
-          if (PC) dnp = (p == 16) ? dnpc : dnp;
+          if (PC && !LAZY) dnp = (p == 16) ? dnpc : dnp;
           if (TB) sgp = (p >= 32) ? sg_x : 1.0;   // violated side of a torque row
           need_pick = false;
         }
@@ -516,6 +536,13 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     if (live) iters++;
     WBC_GI_STAT(if (h == 0 && live) g_gi_generic_trips++);
     if (!takeover) {
+      if constexpr (LAZY) {
+        // a robot that is adding the dense row (a fresh pick, or the same row again after a blocked step: the basis has moved) builds its image now
+        if (qo.wave_any(live && p == 16)) {
+          const double n2 = dense_image(Dpc);
+          dnp = (p == 16) ? n2 : dnp;
+        }
+      }
 #pragma unroll
       for (int k = 0; k < NV; k++) {
         if (TB) d[k] = sgp * d[k];
@@ -527,7 +554,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       for (int k = 0; k < NV; k++) {
         zd = fmad(Jr[k], dm[k], zd);
         sd = fmad(Dh[k], dm[k], sd);
-        if (PC) sdpc = fmad(Dpc[k], dm[k], sdpc);
+        if (PC && !LAZY) sdpc = fmad(Dpc[k], dm[k], sdpc);
         if (TB) sdt = fmad(Dt[k], dm[k], sdt);
       }
       // dual step direction r = R^-1 d[0:q]: every active row's lane holds its row of W = R^-1
@@ -583,7 +610,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       const double tz = (dependent || !go) ? 0.0 : t;
       z = fmad(tz, zd, z);
       sh_ = fmad(tz, sd, sh_);
-      if (PC) spc = fmad(tz, sdpc, spc);
+      if (PC && !LAZY) spc = fmad(tz, sdpc, spc);
       if (TB) yt = fmad(tz, sdt, yt);
       sp = go ? fmad(tz, d2n, sp) : sp;
     }
@@ -616,7 +643,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         wj = fmad(Jr[k], w[k], wj);
         wdh = fmad(Dh[k], w[k], wdh);
         ww = fmad(Wr[k], w[k], ww);
-        if (PC) { wp1 = fmad(Dpc[k], w[k], wp1); wp2 = fmad(Wpc[k], w[k], wp2); }
+        if (PC) { if (!LAZY) wp1 = fmad(Dpc[k], w[k], wp1); wp2 = fmad(Wpc[k], w[k], wp2); }
         if (TB) { wt1 = fmad(Dt[k], w[k], wt1); wt2 = fmad(Wt[k], w[k], wt2); }
       }
 #pragma unroll
@@ -649,7 +676,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       hv[k] = fmad(-alpha, eq[k], x[k]);   // entry q: x_q - alpha
       jq = fmad(eq[k], Jr[k], jq);
       dhq = fmad(eq[k], Dh[k], dhq);
-      if (PC) dpq = fmad(eq[k], Dpc[k], dpq);
+      if (PC && !LAZY) dpq = fmad(eq[k], Dpc[k], dpq);
       if (TB) dtq = fmad(eq[k], Dt[k], dtq);
     }
     const double wj_ = fmad(-alpha, jq, c_j) * beta, wd = fmad(-alpha, dhq, c_d) * beta;
@@ -658,7 +685,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     for (int k = 0; k < NV; k++) {
       Jr[k] = fmad(-wj_, hv[k], Jr[k]);
       Dh[k] = fmad(-wd, hv[k], Dh[k]);
-      if (PC) Dpc[k] = fmad(-wp, hv[k], Dpc[k]);
+      if (PC && !LAZY) Dpc[k] = fmad(-wp, hv[k], Dpc[k]);
       if (TB) Dt[k] = fmad(-wt, hv[k], Dt[k]);
     }
     if (anyd) {
@@ -737,6 +764,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   if (wave_dropped) {
     // inhomogeneous rows (dense row: n.z = vc pc_inv;  torque row: (sig Tn).z = -bt - sig t0n) put g = sum beta_a W_a into the used slots
     double yk[NV], g[NV];
+    if constexpr (LAZY) { if (qo.wave_any(act_pc)) (void)dense_image(Dpc); }   // (lane (0, 3) carries y in its row slots and has no entry in the dense row's normal)
     const double b_pc = (PC && act_pc) ? vc * pc_inv : 0.0, b_t = (TB && act_t) ? -(bt + sig_t * t0n) : 0.0;
 #pragma unroll
     for (int k = 0; k < NV; k++) {

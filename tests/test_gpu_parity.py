@@ -518,3 +518,20 @@ def test_sub_batch_with_leading_dimension():
     assert ctrl._L.wbc_step(ctrl._h, n, (1 << 23) + 1, P(q, 0), P(v, 0), P(tg, 0), P(mask, 0), None, None, P(tau, 0), None, None) < 0
     assert b"WBC_MAX_LD" in ctrl._L.wbc_last_error()
     ctrl.close()
+
+
+def test_clf_row_active_on_the_device():
+    """The CLF law's dense row (its decrease condition, reference clf_controller.py:198-209) never binds on the BASELINE batches; with body targets
+    pushed 20 x further from the state it does for a few robots of the batch.  Round 5 builds that row's image lazily (csrc/wbc_hex.hpp: LAZY,
+    profiles/r05/lazy_dense.md) -- only in a trip that adds it -- so the trips that do add it are checked against the oracle here."""
+    from oracle import oracle_py as orc
+    from quadruped_drake_amd import workloads
+    b = workloads.make_batch(3, n=1024)
+    tg = b["targets"].copy()
+    tg[0:6] = b["targets"][0:6] + (b["targets"][0:6] - b["targets"][0:6].mean(1, keepdims=True)) * 19.0
+    tau, met, st, _ = gpu_step("clf", b["model"], b["q"], b["v"], tg, b["mask"], b["mu"], b["mass_scale"])
+    tau_o, met_o, st_o = orc.step_batch("clf", orc.model(b["model"]), orc.params("clf"), b["q"], b["v"], tg, b["mask"], b["mu"], b["mass_scale"])
+    assert np.array_equal(st, st_o) and (st == 0).all()
+    assert rel_err(tau, tau_o).max() < TOL_TROT
+    # (how many walks add the row is counted on the host: tests/test_kernel_math_host.py::test_clf_row_built_lazily)
+    assert np.allclose(met, met_o, rtol=1e-6, atol=1e-6 * np.abs(met_o).max())

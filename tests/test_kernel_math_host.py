@@ -397,3 +397,46 @@ def test_pick_rule_by_contact_count_on_the_dense_row_laws(tmp_path):
         tau_new, _, st, it_new = ht.run(kind, orc.load_model_json(bs["model"])["flat"], bs["q"], bs["v"], bs["targets"], bs["mask"], hexv=True)
         tau_old, st_old, it_old = run_old(kind, bs)
         assert np.array_equal(tau_new, tau_old) and np.array_equal(it_new, it_old) and np.array_equal(st, st_old)
+
+
+def test_clf_row_built_lazily(tmp_path):
+    """Round 5 (csrc/wbc_hex.hpp: LAZY; profiles/r05/lazy_dense.md): CLF takes its dense row's VALUE fresh from z at every pick and builds the row's image
+    only in a trip that adds it, instead of reflecting the image through every trip.  Against a build that reflects it (-DWBC_LAZY_DENSE=0): bit-identical
+    where the row never binds (the BASELINE batches), the same solution to 1e-10 where it does (body targets pushed 20 x further out: the walk of a few
+    robots adds the row), and both within 1e-7 of the oracle."""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dp = C.POINTER(C.c_double)
+    so = str(tmp_path / "libhost_nolazy.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", "-DWBC_LAZY_DENSE=0",
+                           "-o", so, os.path.join(root, "tools", "host_tick.cpp")])
+    old = C.CDLL(so)
+
+    def run_old(b, tg):
+        n = b["q"].shape[1]
+        t = orc.load_model_json(b["model"])
+        q, v, tg = (np.ascontiguousarray(x) for x in (b["q"], b["v"], tg))
+        flat = np.ascontiguousarray(t["flat"], dtype=np.float64)
+        tau = np.zeros((12, n)); met = np.zeros((4, n)); st = np.zeros(n, np.int32); it = np.zeros(n, np.int32)
+        rc = old.host_hex_batch(3, flat.ctypes.data_as(dp), None, None, None, n, n, q.ctypes.data_as(dp), v.ctypes.data_as(dp), tg.ctypes.data_as(dp),
+                                b["mask"].ctypes.data_as(C.POINTER(C.c_ubyte)), None, None, tau.ctypes.data_as(dp), met.ctypes.data_as(dp),
+                                st.ctypes.data_as(C.POINTER(C.c_int)), it.ctypes.data_as(C.POINTER(C.c_int)))
+        assert rc == 0
+        return tau, st, it
+
+    b = workloads.make_batch(3, n=64)
+    flat = orc.load_model_json(b["model"])["flat"]
+    tau_new, _, st, it_new = ht.run("clf", flat, b["q"], b["v"], b["targets"], b["mask"], hexv=True)
+    tau_old, st_old, it_old = run_old(b, b["targets"])
+    assert np.array_equal(tau_new, tau_old) and np.array_equal(it_new, it_old) and np.array_equal(st, st_old)     # the row never binds here
+    tg = b["targets"].copy()
+    tg[0:6] = b["targets"][0:6] + (b["targets"][0:6] - b["targets"][0:6].mean(1, keepdims=True)) * 19.0
+    tau_new, _, st, it_new = ht.run("clf", flat, b["q"], b["v"], tg, b["mask"], hexv=True)
+    tau_old, st_old, it_old = run_old(b, tg)
+    differ = (np.abs(tau_new - tau_old).max(0) > 0).sum()
+    assert 1 <= differ <= 16 and rel_err(tau_new, tau_old).max() < 1e-10          # a few walks add the row: a freshly built image instead of a reflected one
+    assert np.array_equal(it_new, it_old) and np.array_equal(st, st_old) and (st == 0).all()
+    tau_o, _, st_o = orc.step_batch("clf", orc.model(b["model"]), orc.params("clf"), b["q"], b["v"], tg, b["mask"])
+    assert (st_o == 0).all() and rel_err(tau_new, tau_o).max() < 1e-7 and rel_err(tau_old, tau_o).max() < 1e-7
