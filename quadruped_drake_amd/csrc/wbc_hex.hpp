@@ -787,7 +787,9 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
     for (int k = 0; k < NV; k++) {
       double c = qo.sum16(TB ? fmad(nu_t, Dt[k], nu * Dh[k]) : nu * Dh[k]);
-      if (PC) c = fmad(nu_pc, Dpc[k], c);
+      // LAZY: Dpc holds an image only where dense_image() has just built it (a wavefront with an active dense row); anywhere else it is
+      // unwritten storage, and 0 * garbage is not 0 when the garbage is a NaN pattern -- select, never multiply
+      if (PC) c = fmad(nu_pc, (!LAZY || act_pc) ? Dpc[k] : 0.0, c);
       const double yh = mk[k] * (yk[k] - c);
       zr = fmad(Jr[k], (PC || TB) ? yh + g[k] : yh, zr);
     }

@@ -440,3 +440,52 @@ def test_clf_row_built_lazily(tmp_path):
     assert np.array_equal(it_new, it_old) and np.array_equal(st, st_old) and (st == 0).all()
     tau_o, _, st_o = orc.step_batch("clf", orc.model(b["model"]), orc.params("clf"), b["q"], b["v"], tg, b["mask"])
     assert (st_o == 0).all() and rel_err(tau_new, tau_o).max() < 1e-7 and rel_err(tau_old, tau_o).max() < 1e-7
+
+
+def test_no_unwritten_storage_feeds_the_arithmetic(tmp_path):
+    """Round 6: under LAZY the CLF law's dense-row image Dpc[] is written only where the row is being added or is active, and the
+    evaluation after a drop multiplied it by a zero multiplier everywhere else -- 0 x stale storage, which is NaN whenever the stale bits are a NaN
+    pattern (status 0, NaN torques on 178 of 256 stands when poisoned).  The host instantiation of the same header, compiled by clang once as it is
+    and once with every automatic variable pre-filled with the 0xFF..FF pattern (a NaN for a double), must give the same bits on the drop-heavy
+    stands and on the trots of every law, with and without the torque box: no value that was never written reaches an instruction that computes.
+    (Both builds by the same compiler: gcc and clang round a handful of unannotated expressions differently, 1e-10 on the torques.)"""
+    import ctypes as C
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no clang++ for -ftrivial-auto-var-init=pattern")
+    libs = []
+    for name, extra in (("plain", []), ("poison", ["-ftrivial-auto-var-init=pattern"])):
+        so = str(tmp_path / ("libhost_tick_%s.so" % name))
+        subprocess.check_call([clang, "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off"] + extra +
+                              ["-o", so, os.path.join(root, "tools", "host_tick.cpp")])
+        libs.append(C.CDLL(so))
+    dp = C.POINTER(C.c_double)
+    names = ("Kp_body_p", "Kd_body_p", "Kp_body_rpy", "Kd_body_rpy", "Kp_foot", "Kd_foot", "w_body", "w_foot", "mu", "Kd_contact", "tau_max", "tiebreak_eps2")
+    n = 128
+    for cfg, kind, k, tmax in ((2, "clf", 3, None), (3, "clf", 3, None), (2, "pc", 2, None), (3, "pc", 2, None), (2, "id", 0, None), (2, "mptc", 1, None),
+                               (3, "mptc", 1, None), (2, "clf", 3, 12.0), (2, "id", 0, 8.0)):
+        b = workloads.make_batch(cfg, n=n)
+        t = orc.load_model_json(b["model"])
+        pp = None
+        if tmax is not None:
+            p = orc.params(kind); p.tau_max = tmax
+            pp = np.array([getattr(p, f) for f in names], dtype=np.float64)
+        q, v, tg = (np.ascontiguousarray(b[x]) for x in ("q", "v", "targets"))
+        flat = np.ascontiguousarray(t["flat"], dtype=np.float64)
+        out = []
+        for L in libs:
+            tau = np.zeros((12, n)); met = np.zeros((4, n)); st = np.zeros(n, np.int32); it = np.zeros(n, np.int32)
+            rc = L.host_hex_batch(k, flat.ctypes.data_as(dp), pp.ctypes.data_as(dp) if pp is not None else None, None, None, n, n, q.ctypes.data_as(dp),
+                                  v.ctypes.data_as(dp), tg.ctypes.data_as(dp), b["mask"].ctypes.data_as(C.POINTER(C.c_ubyte)), None, None,
+                                  tau.ctypes.data_as(dp), met.ctypes.data_as(dp), st.ctypes.data_as(C.POINTER(C.c_int)), it.ctypes.data_as(C.POINTER(C.c_int)))
+            assert rc == 0
+            out.append((tau, met, st, it))
+        (tau, met, st, it), (tau_p, met_p, st_p, it_p) = out
+        assert np.isfinite(tau_p).all() and np.isfinite(met_p).all(), (cfg, kind, int(np.isnan(tau_p).any(0).sum()))
+        assert np.array_equal(st, st_p) and np.array_equal(it, it_p), (cfg, kind, tmax)
+        assert np.array_equal(tau, tau_p) and np.array_equal(met, met_p), (cfg, kind, tmax)
+        if cfg == 2:
+            assert it.mean() > 8          # drop-heavy: the evaluation after a drop runs
