@@ -45,7 +45,7 @@ PMC_ROUND = "r05"                                  # profiles/<round>/hex_pmc.js
 # what the identity of a kernel build covers: an explicit list (a stray backup file under csrc/ does not change it)
 KERNEL_SOURCES = ["quadruped_drake_amd/csrc/hipcc_flags.txt", "quadruped_drake_amd/csrc/wbc_hex.hpp", "quadruped_drake_amd/csrc/wbc_kernels.hip",
                   "quadruped_drake_amd/csrc/wbc_model.hpp", "quadruped_drake_amd/csrc/wbc_tick.hpp", "quadruped_drake_amd/csrc/wbc_traj.hip",
-                  "quadruped_drake_amd/csrc/wbc_traj_dev.hpp", "include/wbc.h", "include/wbc_extras.h"]
+                  "quadruped_drake_amd/csrc/wbc_traj_dev.hpp", "quadruped_drake_amd/csrc/wbc_device_guard.hpp", "include/wbc.h", "include/wbc_extras.h"]
 
 
 def kernel_src_sha16():

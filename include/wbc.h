@@ -31,9 +31,26 @@
  * Joint rows of q/v are mapped through model.q_perm (canonical joint j is read from joint row
  * q_perm[j]); torque row k is canonical joint act_perm[k]  (basic_controller.py:310-313).
  *
+ * Malformed instances: the reference asserts on a failed solve and hands NaN on through numpy; a batch cannot.  An instance is
+ * reported with status 2 -- zero torques, zero accelerations, zero metrics -- when the
+ * tick cannot answer it with finite numbers:
+ *   - a value that is not a finite number (NaN, +-inf) in anything the law READS: q, v, the body targets, the targets of the SWING
+ *     feet (a contact foot's target rows are not read -- the reference indexes p_feet_nom[swing_feet],
+ *     inverse_dynamics_controller.py:152-154 -- and may hold anything), mu, mass_scale;
+ *   - mu or mass_scale not a positive finite number;
+ *   - a quaternion without a direction (zero, or so small / large that |q|^2 under- or overflows; any other quaternion stands for
+ *     its normalised self: Drake's RotationMatrix(quaternion) scales by 2/|q|^2, and so do the kernels);
+ *   - finite inputs whose torques or metrics overflow on the way (targets of 1e200 ...).
+ * No output of a tick is ever NaN or inf.  The other instances of the batch -- including the three that share its wavefront -- are
+ * computed exactly as if it were not there (bit-identical; tests/test_robustness_gpu.py), and in a closed-loop rollout such an
+ * instance is reported on every tick for which the condition holds (its state is integrated with zero accelerations meanwhile)
+ * without touching its neighbours.  contact_mask: only bits 0..3 are read.
+ *
  * Error convention: every function returns 0 on success, <0 on API misuse or a HIP error;
  * nothing throws.  wbc_last_error() returns a thread-local message.
  * Threading: a handle is not thread-safe; distinct handles are independent (one per GPU).
+ * Current device: every call runs on its handle's device and leaves the calling thread's current HIP device as it found it
+ * (hipGetDevice before == after), so handles on several GPUs can be driven from one thread and torch's current device is not moved.
  * wbc_step is asynchronous on the handle's stream; wbc_sync blocks.  No allocation in wbc_step.
  */
 #ifndef WBC_H
@@ -67,7 +84,11 @@ extern "C" {
                               them: wbc_sync, or the next wbc_step / wbc_set_stream on the handle (each first collects a
                               pending result).  Waiting on the stream or on an event of one's own does NOT: for n <= 64 the
                               copy into the caller's arrays is host code that runs inside those calls.  wbc_destroy waits
-                              for the device but ABANDONS an uncollected result: it never writes into caller-owned memory */
+                              for the device and delivers nothing itself -- but what that means differs by batch size:
+                              n <= 64: an uncollected result is ABANDONED (the caller's arrays are not written);
+                              n > 64: the device-to-host copies into the caller's arrays were queued by wbc_step itself and
+                              COMPLETE while wbc_destroy waits.  So: the output arrays of the last wbc_step must stay
+                              allocated until wbc_sync or wbc_destroy has returned, whatever the batch size */
 
 /* Kinematic tree + inertias, as produced by tools/compile_model.py from the reference's URDFs
  * (models/mini_cheetah/mini_cheetah_mesh.urdf, models/anymal_b_simple_description/urdf/anymal_drake.urdf):

@@ -1100,6 +1100,53 @@ int orc_clf_control_law(const orc_model* m, const orc_params* p, const double* q
 }
 
 /* ------------------------------------------------------------------ batched driver */
+/* The product's convention for instances that cannot be answered with finite numbers (include/wbc.h "Malformed instances"), MIRRORED here like status 3
+ * so that checker and checked can be compared instance by instance (g_product_status; the reference itself asserts, inverse_dynamics_controller.py:224,
+ * or hands NaN on): a value that is not a finite number in anything the law READS -- q, v, the body targets, the targets of the SWING feet (the
+ * reference indexes p_feet_nom[swing_feet], inverse_dynamics_controller.py:152-154: a contact foot's targets are never read) --, a mu or mass scale
+ * that is not a positive finite number, or finite inputs whose torques or metrics overflow -> status 2, zero torques, zero metrics. */
+static int not_finite(double x) { return !(fabs(x) < HUGE_VAL); }
+static int malformed_instance(const double* q, const double* v, const double* tg, const int* ct, double mu, double ms) {
+  for (int k = 0; k < 19; k++) if (not_finite(q[k])) return 1;
+  for (int k = 0; k < 18; k++) if (not_finite(v[k])) return 1;
+  for (int k = 0; k < 18; k++) if (not_finite(tg[k])) return 1;
+  for (int f = 0; f < 4; f++)
+    if (!ct[f]) for (int k = 0; k < 9; k++) if (not_finite(tg[18 + 9 * f + k])) return 1;
+  if (!(mu > 0.0) || not_finite(mu) || !(ms > 0.0) || not_finite(ms)) return 1;
+  double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  return !(n2 > 0.0) || not_finite(n2);   /* a quaternion without a direction: 2 / |q|^2 is inf or 0 x inf */
+}
+static int one_instance(const orc_model* m, const orc_params* p, int kind, const double* qi, const double* vi, const double* tg, const int* ct,
+                        double mu_i, double ms_i, double* ti, double* mi) {
+  double tgs[54];
+  if (g_product_status) {
+    if (malformed_instance(qi, vi, tg, ct, mu_i, ms_i)) {
+      for (int k = 0; k < 12; k++) ti[k] = 0.0;
+      for (int k = 0; k < 4; k++) mi[k] = 0.0;
+      return 2;
+    }
+    /* what the law does not read may hold anything (the restatement below multiplies some of it by a zero weight, which a NaN survives) */
+    memcpy(tgs, tg, sizeof tgs);
+    for (int f = 0; f < 4; f++)
+      if (ct[f]) for (int k = 0; k < 9; k++) if (not_finite(tgs[18 + 9 * f + k])) tgs[18 + 9 * f + k] = 0.0;
+    tg = tgs;
+  }
+  int st = (kind == 0) ? orc_id_control_law(m, p, qi, vi, tg, ct, ti, mi, NULL)
+           : (kind == 1) ? orc_mptc_control_law(m, p, qi, vi, tg, ct, ti, mi, NULL)
+           : (kind == 2) ? orc_pc_control_law(m, p, qi, vi, tg, ct, ti, mi, NULL)
+                         : orc_clf_control_law(m, p, qi, vi, tg, ct, ti, mi, NULL);
+  if (g_product_status) {
+    int bad = 0;
+    for (int k = 0; k < 12; k++) bad |= not_finite(ti[k]);
+    bad |= not_finite(mi[0] + mi[1] + mi[3]);
+    if (bad) st = 2;
+    if (st == 2) {   /* the product reports zeros throughout for an instance it could not answer */
+      for (int k = 0; k < 12; k++) ti[k] = 0.0;
+      for (int k = 0; k < 4; k++) mi[k] = 0.0;
+    }
+  }
+  return st;
+}
 int orc_step_batch(const orc_model* m, const orc_params* p, int kind, int n, int stride, const double* q,
                    const double* v, const double* targets, const unsigned char* mask, const double* mu,
                    const double* mass_scale, double* tau, double* metrics, int* status, int nthreads) {
@@ -1123,10 +1170,7 @@ int orc_step_batch(const orc_model* m, const orc_params* p, int kind, int n, int
       ml.base_mass *= mass_scale[i];
       for (int k = 0; k < 6; k++) ml.base_I[k] *= mass_scale[i];
     }
-    int st = (kind == 0) ? orc_id_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
-             : (kind == 1) ? orc_mptc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
-             : (kind == 2) ? orc_pc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
-                           : orc_clf_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL);
+    int st = one_instance(&ml, &pl, kind, qi, vi, tg, ct, pl.mu, mass_scale ? mass_scale[i] : 1.0, ti, mi);
     for (int k = 0; k < 12; k++) tau[(size_t)k * stride + i] = ti[k];
     if (metrics) for (int k = 0; k < 4; k++) metrics[(size_t)k * stride + i] = mi[k];
     if (status) status[i] = st;
@@ -1161,10 +1205,7 @@ int orc_bench_batch(const orc_model* m, const orc_params* p, int kind, int n, in
       ml.base_mass *= mass_scale[i];
       for (int k = 0; k < 6; k++) ml.base_I[k] *= mass_scale[i];
     }
-    int st = (kind == 0) ? orc_id_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
-             : (kind == 1) ? orc_mptc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
-             : (kind == 2) ? orc_pc_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL)
-                           : orc_clf_control_law(&ml, &pl, qi, vi, tg, ct, ti, mi, NULL);
+    int st = one_instance(&ml, &pl, kind, qi, vi, tg, ct, pl.mu, mass_scale ? mass_scale[i] : 1.0, ti, mi);
     if (j >= total - n) {
       for (int k = 0; k < 12; k++) tau[(size_t)k * stride + i] = ti[k];
       if (status) status[i] = st;

@@ -22,11 +22,6 @@
 #include <type_traits>
 #include <utility>
 #include "wbc_tick.hpp"
-// WBC_QRF bit 0: hardware-seeded sqrt in the Householder steps; bit 1: the same for the reciprocal (round 1: bit 1
-// made the MPTC kernel spill; with the single 30-row append of round 2 it does not and saves ~140 instructions)
-#ifndef WBC_QRF
-#define WBC_QRF 3
-#endif
 
 // host-only diagnostics (tools/host_tick.cpp): how many fast / generic active-set trips a robot ran
 #if !defined(__HIPCC__) && defined(WBC_HOST_GI_STATS)
@@ -71,14 +66,10 @@ WBC_HD constexpr int hex_lane(int k) { return k < 12 ? 4 * (k / 3) + (k % 3) : H
 // saturated stands (profiles/r04/accuracy.md).  Order: the three vertical forces z0 z1 z2 (force z, moments x and y), x0 y0
 // (forces x, y), y2 (the yaw moment: left-front and left-hind differ in x) -- six independent wrench columns on any stance --
 // then the rest.  Trots keep their structure (one eps-sized pivot, last or followed by swing variables as before).
-#ifndef WBC_NATURAL_PIVOTS
 WBC_HD constexpr int hex_piv(int k) {
   constexpr int order[13] = {2, 5, 8, 0, 1, 7, 3, 4, 6, 9, 10, 11, 12};
   return order[k];
 }
-#else
-WBC_HD constexpr int hex_piv(int k) { return k; }
-#endif
 WBC_HD constexpr int hex_piv_lane(int k) { return hex_lane(hex_piv(k)); }   // lane that owns the k-th pivot column
 
 // Distributed Householder append: fold P dense rows into the upper-triangular factor.
@@ -114,18 +105,10 @@ WBC_HD void hex_qr_append(Q& qo, double* Rcol, double* Acol) {
     const double t = (ta + tb) + tc;
     const double s2 = qo.bcast16(t, piv);
     const double rkk = qo.bcast16(Rcol[k], piv);
-#if WBC_QRF & 1
-    const double nrm = fast_sqrt(rkk * rkk + s2);
-#else
-    const double nrm = sqrt(rkk * rkk + s2);
-#endif
+    const double nrm = fast_sqrt(rkk * rkk + s2);   // hardware-seeded root and reciprocal (wbc_tick.hpp)
     const double alpha = (rkk > 0.0) ? -nrm : nrm;
     const double v0 = rkk - alpha;
-#if WBC_QRF & 2
-    const double beta = (s2 > 0.0) ? fast_rcp(nrm * (nrm + fabs(rkk))) : 0.0;
-#else
-    const double beta = (s2 > 0.0) ? 1.0 / (nrm * (nrm + fabs(rkk))) : 0.0;
-#endif  // = 2 / (s2 + v0^2); empty column: no-op
+    const double beta = (s2 > 0.0) ? fast_rcp(nrm * (nrm + fabs(rkk))) : 0.0;  // = 2 / (s2 + v0^2); empty column: no-op
     const double ns = -((v0 * Rcol[k] + t) * beta);
     Rcol[k] += ns * v0;
     static_for<P>([&](auto I) { Acol[I] = qo.template fma_bc<piv>(Acol[I], Acol[I], ns); });
@@ -162,13 +145,8 @@ WBC_HD int hex_key_index(double k) {
 // device and from build to build, and one of the two choices ends in a blocked step: a drop and a re-add, on the device two generic trips for
 // the whole wavefront (the slowest wavefront of the headline launch was such a robot; profiles/r05/apex_rule.md).  The pick only needs
 // SOME violated row, the exact value of the picked row is fetched from its lane; the blocking-ratio keys (hex_pack_key) stay at 2^-47.
-#ifndef WBC_LAZY_DENSE
-#define WBC_LAZY_DENSE 1   // dense-row laws: the dense row's image is built when it is needed, not reflected every trip (hex_gi)
-#endif
-#ifndef WBC_PICK_BITS
-#define WBC_PICK_BITS 24
-#endif
-template <int BITS = WBC_PICK_BITS> WBC_HD double hex_pack_pick(double v, int idx) {
+constexpr int HEX_PICK_BITS = 24;
+template <int BITS = HEX_PICK_BITS> WBC_HD double hex_pack_pick(double v, int idx) {
   unsigned long long b;
   __builtin_memcpy(&b, &v, 8);
   b = (b & ~((1ull << BITS) - 1ull)) | (unsigned long long)((31 - idx) & 31);
@@ -219,19 +197,17 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   }
   sh_ = sg * qo.leg_pairs(z) + mu_n * qo.leg_bcast(z, 2);
   const double npl = PC ? -vrow_own * pc_inv : 0.0;   // own entry of the dense row's normal
-#ifndef WBC_NO_DROP_REFINE
   // Lane (0, 3) owns no row of J: its Jr[] carries y = Q'b through the reflections (the evaluation after a drop, below), and z there
   // accumulates a meaningless y . d.  That is harmless only while every 16-lane reduction over Jr or z is masked off that lane: the
   // dense row's normal, the torque rows' normals and the tolerance's |z| are zero there by construction -- checked on the host.
-  WBC_HOST_ASSERT(h != 3 || (vrow_own == 0.0 && npl == 0.0 && z == 0.0));
+  WBC_HOST_ASSERT(h != 3 || ((vrow_own == 0.0 || vrow_own != vrow_own) && (npl == 0.0 || npl != npl) && (z == 0.0 || z != z)));   // (NaN: a malformed instance on its way to the output stage's sentinel)
   if (TB) { for (int c = 0; c < NZ; c++) WBC_HOST_ASSERT(hex_lane(c) != 3); }   // the torque rows read Jr / z of column lanes only
-#endif
   double Dpc[NV], spc = 0.0, dnpc = 0.0, u_pc = 0.0;
   bool act_pc = false;
   // The dense row (PC: Vdot <= 0, CLF: its decrease condition) is inactive on most robots and most ticks.  LAZY: instead of reflecting its image D_pc through
   // every trip (and building it up front: thirteen 16-lane sums), its VALUE is taken fresh from the current z at every pick (one 16-lane sum) and its image is
   // built from the current rows of J only in a trip that adds it (or, for the evaluation after a drop, while it is active): profiles/r05/lazy_dense.md.
-  constexpr bool LAZY = PC && (NV != NZ) && (WBC_LAZY_DENSE != 0);   // CLF (13 slots): -4 ... -5 %; PC measured no gain (its trips are mostly fast-path ones) and keeps the reflected image
+  constexpr bool LAZY = PC && (NV != NZ);   // CLF (13 slots): -4 ... -5 %; PC measured no gain (its trips are mostly fast-path ones) and keeps the reflected image
   auto dense_value = [&]() -> double { return -(qo.sum16(vrow_own * z) + vc) * pc_inv; };
   auto dense_image = [&](double* D) -> double {
     double n2 = 0.0;
@@ -278,13 +254,9 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   // active is therefore not a candidate.  nleg = active friction rows of the own leg (replicated on its four lanes).
   // (Friction-only instantiations -- ID, MPTC, with or without the torque box: the dense-row laws PC / CLF carry their Dpc / Wpc arrays through the same
   // trips and measured 2 % slower with the bookkeeping than they gain -- their picks still get the deterministic tie-break of hex_pack_pick.)
-#ifndef WBC_NO_APEX_RULE
   constexpr bool APEX = !PC;
-#else
-  constexpr bool APEX = false;
-#endif
   // dense-row laws: the keys of rounds 1-4 unchanged (anything else costs the CLF torque-box rollout kernel, at 486 registers, its last ones: 8 B/lane of scratch)
-  auto pick_pack = [](double v, int idx) -> double { if constexpr (PC) return hex_pack_key(v, idx); else return hex_pack_pick<WBC_PICK_BITS>(v, idx); };
+  auto pick_pack = [](double v, int idx) -> double { if constexpr (PC) return hex_pack_key(v, idx); else return hex_pack_pick<HEX_PICK_BITS>(v, idx); };
   auto pick_pack_fine = [](double v, int idx) -> double { if constexpr (PC) return hex_pack_key(v, idx); else return hex_pack_pick<5>(v, idx); };
   auto pick_index = [](double k) -> int { if constexpr (PC) return hex_key_index(k); else return hex_pick_index(k); };
   int nleg = 0;
@@ -303,16 +275,8 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   // it has changed any state and the generic loop below takes over.  Both paths evaluate the same expressions in the
   // same order, so a robot's result does not depend on which path its wavefront took (bit-identical; tests:
   // batch-position invariance).
-#ifndef WBC_QF_ID
-#define WBC_QF_ID 8
-#endif
-#ifndef WBC_CLF_FAST
-#define WBC_CLF_FAST 0   // CLF (13 slots) through the fast path too: built, bit-identical, measured -1 ... +3 % (profiles/r05/hybrid_pick.md): off
-#endif
-#ifndef WBC_HYBRID_PICK
-#define WBC_HYBRID_PICK 1   // dense-row laws (PC, CLF): pick rule by contact count (hex_gi)
-#endif
-  constexpr int QF = (!TB && (NV == NZ || WBC_CLF_FAST)) ? (GAIN ? 8 : WBC_QF_ID) : 0;   // ID stands add up to 8-12 rows before the first drop; PC: see pcv below
+  // (CLF, 13 slots, through the fast path too: built, bit-identical, measured -1 ... +3 %, profiles/r05/hybrid_pick.md -- not taken)
+  constexpr int QF = (!TB && NV == NZ) ? 8 : 0;   // fast-path bodies; ID stands add up to 8-12 rows before the first drop (12 bodies measured slower); PC: see pcv below
   // Which inactive row to add -- Goldfarb-Idnani may take any violated one.  Greatest dual gain s^2 / |free part|^2 (GAIN) needs fewer trips where few rows
   // end up active (one or two feet down: -12 ... -30 % trips), the most violated row needs fewer on saturated stands (four feet: -4 ... -7 % trips and no
   // gain arithmetic: -15 % launch time); three feet: a wash (host emulation by contact count, profiles/r05/hybrid_pick.md).  HYB: the rule is chosen PER
@@ -359,7 +323,6 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       }
       // PC law: the dense row (Vdot <= 0) is never added here -- a robot whose dense row is violated sends the wavefront to the
       // generic loop (rare: ~5 % of the robots); while it is inactive the fast trips only carry its image and value along
-      if constexpr (LAZY && qc > 0) { if (pc) spc = dense_value(); }
       const bool pcv = PC && pc && spc < -tol;
       // every wavefront's last trip finds nothing left to repair anywhere: leave before the crossbar round trip
       if (qo.wave_all(done || (pf < 0 && !pcv))) { done = true; stop = true; generic = false; return; }
@@ -394,7 +357,6 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
       const bool full = !dependent && (!have_t1 || !(t1 < t2));
       if (qo.wave_any(!done && (!full || pcpick)) || WBC_GI_FORCE_BAIL(qc)) {   // not a friction add-with-full-step everywhere: generic loop, state untouched
         stop = true;
-#ifndef WBC_NO_HANDOVER
         if constexpr (!PC) {   // (measured on the PC law, whose dense row sends ~20 % of the wavefronts here: +2 % -- not taken over there)
           handed = true;
           ho_p = pf; ho_sp = spx; ho_dn = dnx; ho_d2n = d2n; ho_zd = zd; ho_sd = sd; ho_r = r_h;
@@ -402,7 +364,6 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
 #pragma unroll
           for (int k = 0; k < NV; k++) ho_d[k] = d[k];
         }
-#endif
         return;
       }
       if (!done) {
@@ -421,7 +382,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
         Jr[qc] = fmad(-w, vq, Jr[qc]);
         Dh[qc] = fmad(-wd, vq, Dh[qc]);
         static_for<NV - qc - 1>([&](auto KK) { constexpr int k = qc + 1 + KK; Jr[k] = fmad(-w, d[k], Jr[k]); Dh[k] = fmad(-wd, d[k], Dh[k]); });
-        if (PC && !LAZY) {
+        if (PC) {   // (PC only: the CLF law, whose dense row is built lazily, has no fast path -- QF = 0 for 13 slots)
           double sdpc = 0.0;
           static_for<NV - qc>([&](auto KK) { constexpr int k = qc + KK; sdpc = fmad(Dpc[k], d[k], sdpc); });
           spc = fmad(t2, sdpc, spc);
@@ -760,7 +721,6 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   // (every trot) there is one, and the robots of a trot batch that drop a row are within 1e-12 of the extended-precision oracle
   // either way (measured on 130 of them).  Robots that never dropped keep the accumulated z; the code runs when any deep robot of
   // the wavefront has dropped, and a robot's result does not depend on its wave-mates.
-#ifndef WBC_NO_DROP_REFINE
   if (wave_dropped) {
     // inhomogeneous rows (dense row: n.z = vc pc_inv;  torque row: (sig Tn).z = -bt - sig t0n) put g = sum beta_a W_a into the used slots
     double yk[NV], g[NV];
@@ -795,11 +755,8 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
     }
     z = dropped ? zr : z;
   }
-#endif
   }   // generic
-#ifndef WBC_NO_DROP_REFINE
   z = (h == 3) ? 0.0 : z;   // lane (0, 3): y . d garbage (see the entry check); no 16-lane reduction downstream may pick it up
-#endif
   *iters_out = iters;
   if (!done && status == ST_OK) status = ST_ITER;
   return status;
@@ -895,7 +852,9 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
   double R0[9];
   {
     const double qw = in(0), qx = in(1), qy = in(2), qz = in(3);
-    const double s = 2.0 * fast_rcp(qw * qw + qx * qx + qy * qy + qz * qz);
+    const double qn2 = qw * qw + qx * qx + qy * qy + qz * qz;
+    // Drake's RotationMatrix(quaternion) scales by 2 / |q|^2: any non-zero finite quaternion stands for its normalised self; a zero one for nothing
+    const double s = 2.0 * fast_rcp(qn2);
     R0[0] = 1.0 - s * (qy * qy + qz * qz); R0[1] = s * (qx * qy - qw * qz); R0[2] = s * (qx * qz + qw * qy);
     R0[3] = s * (qx * qy + qw * qz); R0[4] = 1.0 - s * (qx * qx + qz * qz); R0[5] = s * (qy * qz - qw * qx);
     R0[6] = s * (qx * qz - qw * qy); R0[7] = s * (qy * qz + qw * qx); R0[8] = 1.0 - s * (qx * qx + qy * qy);
@@ -904,7 +863,9 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
   const double w0[3] = {in(19), in(20), in(21)};
   const double v0[3] = {in(22), in(23), in(24)};
   const double gz = m.gravity;
-  const double bm = m.base_mass * mass_scale;
+  // mu and the mass scale also enter COMPARISONS, which a NaN (or a negative value) passes silently: an instance whose mu or mass scale is not a positive finite
+  // number gets a NaN base mass, which no torque survives (the sentinel of the output stage reports it)
+  const double bm = (!(mu > 0.0) | not_finite(mu) | !(mass_scale > 0.0) | not_finite(mass_scale)) ? __builtin_nan("") : m.base_mass * mass_scale;
   double bmc[3], bI[6];
   {
     const double t[3] = {m.base_mc[0] * mass_scale, m.base_mc[1] * mass_scale, m.base_mc[2] * mass_scale};
@@ -957,11 +918,9 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
       }
     }
   }
-#ifndef WBC_NO_PARK_STATE
   // robot-level values that the leg phase does not touch wait in LDS (the leg phase is the register peak of the tick)
   for (int i = 0; i < 6; i++) { pk.put(PK_ST + i, xt_b[i]); pk.put(PK_ST + 6 + i, xdd_b[i]); pk.put(PK_ST + 12 + i, bI[i]); }
   for (int i = 0; i < 3; i++) pk.put(PK_ST + 18 + i, bmc[i]);
-#endif
   WBC_STAMP(10);
   WBC_HCUT_AT(1, xt_b[0] + xt_b[4] + xdt_b[1] + xdt_b[5] + xdd_b[2] + ades[1] + bI[3] + bmc[1] + R0[5] + rpyd[0] + E[3])
   // ---------------- own leg (replicated on its four sub-lanes unless noted)
@@ -1101,10 +1060,8 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
       Dcol[j] = ct ? -pick3(sb, Jl[j], Jl[3 + j], Jl[6 + j]) : pick3(sb, Pm[3 * j], Pm[3 * j + 1], Pm[3 * j + 2]);
     }
   }
-#ifndef WBC_NO_PARK_STATE
   for (int i = 0; i < 6; i++) { xt_b[i] = pk.get(PK_ST + i); xdd_b[i] = pk.get(PK_ST + 6 + i); bI[i] = pk.get(PK_ST + 12 + i); }
   for (int i = 0; i < 3; i++) bmc[i] = pk.get(PK_ST + 18 + i);
-#endif
   WBC_STAMP(11);
   WBC_HCUT_AT(2, X[0] + X[7] + X[17] + Y[3] + Y[16] + hbN[0] + hbN[5] + lm + lh[1] + lI[3] + Cb_leg[2] + Cl[1] + xi[0] + t0_own + Yrow[2] + Drow[1] + Ji[4] + Mll6[2] + jdxi[0] + xt_s[0] + xdt_s[1] + xt_b[0] + xdt_b[4] + xdd_b[2] + ades[1])
   // ---------------- base: bias wrench, composite inertia -> Gs = G_b, kv
@@ -1461,7 +1418,6 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     pc_inv = (n2 > 0.0) ? 1.0 / sqrt(n2) : 0.0;
   }
   // ... and the rest waits in the lane's LDS slots until the output stage
-#ifndef WBC_NO_LANEPARK
   {
     for (int k = 0; k < 6; k++) { pk.lput(LP_YROW + k, Yrow[k]); pk.lput(LP_BCOL + k, bcol[k]); pk.lput(LP_AB0 + k, ab0[k]); }
     for (int k = 0; k < 3; k++) {
@@ -1474,8 +1430,6 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     pk.lput(LP_MET + 0, vrow_own); pk.lput(LP_MET + 1, vconst); pk.lput(LP_MET + 2, met_V);
     pk.lput(LP_MET + 3, met_Vdot); pk.lput(LP_MET + 4, met_err);
   }
-#endif
-#ifndef WBC_NO_SWING_COMPACT
   // Task-space laws: the swing rows of a contact leg are zero and stay zero under the reflections.  When no robot of the wavefront has
   // more than two swing legs (every trot, every stand) each robot's swing blocks move up into the first two block slots -- selects
   // between registers; blocks move by whole multiples of three rows, so every term keeps its accumulator and its place in the sums:
@@ -1495,9 +1449,9 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     }
     for (int i = 0; i < NZ; i++) A24[12 + i] = Acol[P1 + i];
     hex_qr_append<Q, 24, NV>(qo, Rcol, A24);
-  } else
-#endif
-  hex_qr_append<Q, P1 + NZ, NV>(qo, Rcol, Acol);
+  } else {
+    hex_qr_append<Q, P1 + NZ, NV>(qo, Rcol, Acol);
+  }
   WBC_STAMP(14);
   WBC_HCUT_AT(5, Rcol[0] + Rcol[5] + Rcol[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- own row of J = R^-1 and unconstrained minimiser
@@ -1518,13 +1472,13 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     if (!(rmin > 1e-13 * rmax) || !(rmax < 1e300)) status = ST_SINGULAR;
     if (status == ST_SINGULAR) {
       // reported, not solved: zero torques AND zero accelerations (include/wbc.h: every step writes vd; a rollout
-      // integrates them, so they must be defined)
+      // integrates them, so they must be defined); a malformed instance has no position error to report either
       if (colv) out_tau(m.act_inv[3 * l + sb], 0.0);
-      out_met(0, 0.0); out_met(1, met_err); out_met(2, 0.0); out_met(3, 0.0);
+      out_met(0, 0.0); out_met(1, 0.0); out_met(2, 0.0); out_met(3, 0.0);
       for (int i = 0; i < 6; i++) out_met(4 + i, 0.0);
       if (colv) out_met(4 + 6 + m.q_perm[3 * l + sb], 0.0);
       *iters_out = 0;
-      return status;
+      return ST_SINGULAR;
     }
     // my row index rr = the slot of my variable 3*l + sb (column lanes; 12 on the delta lane).  J[rr][c] = (delta_rr,c - sum_{k<c} J[rr][k] R[k][c]) / R[c][c]
     int rr = NZ;
@@ -1549,12 +1503,10 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     // lane (0, 3) owns no row of J: its row slots carry y = Q'b (the right-hand-side column after the append) through the active
     // set's reflections, for the evaluation of z after a drop (hex_gi)
     // (only a robot with three or four feet down is ever evaluated that way -- `deep` in hex_gi -- so a wavefront of trotting robots skips the copy)
-#ifndef WBC_NO_DROP_REFINE
     if (qo.wave_any(((mask & 1u) + ((mask >> 1) & 1u) + ((mask >> 2) & 1u) + ((mask >> 3) & 1u)) >= 3u)) {
 #pragma unroll
       for (int c = 0; c < NV; c++) Jr[c] = (h == 3) ? Rcol[c] : Jr[c];
     }
-#endif
   }
   WBC_STAMP(15);
   WBC_HCUT_AT(6, z + Jr[0] + Jr[5] + Jr[11] + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
@@ -1567,15 +1519,13 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     (void)s;
     int st;
     if (KIND == KIND_PC) {
-      st = hex_gi<Q, true, NV, TB, WBC_HYBRID_PICK && !TB, true>(qo, h, ct, Jr, z, mu * rs, rs, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt, deep);
+      st = hex_gi<Q, true, NV, TB, !TB, true>(qo, h, ct, Jr, z, mu * rs, rs, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt, deep);
     } else if (KIND == KIND_CLF) {
       // the CLF row  g . [z; delta] - ub <= 0  is the dense row of the active set (index 16), like PC's Vdot row
-      st = hex_gi<Q, true, NV, TB, WBC_HYBRID_PICK && !TB, true>(qo, h, ct, Jr, z, mu * rs, rs, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt, deep);
+      st = hex_gi<Q, true, NV, TB, !TB, true>(qo, h, ct, Jr, z, mu * rs, rs, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt, deep);
     } else {
-#ifndef WBC_GAIN_ID
-#define WBC_GAIN_ID 0
-#endif
-      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC || (WBC_GAIN_ID && KIND == KIND_ID)) && !TB>(qo, h, ct, Jr, z, mu * rs, rs, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt, deep);
+      // pick rule of the friction-only laws, fixed at compile time: MPTC greatest dual gain, ID most violated row (gain pivoting for ID: 12.3 vs 11.4 trips)
+      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC) && !TB>(qo, h, ct, Jr, z, mu * rs, rs, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt, deep);
     }
     if (st != ST_OK) status = st;
     if (status == ST_OK && illc) status = ST_ILLCOND;
@@ -1585,7 +1535,6 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
   WBC_HCUT_AT(7, z + (double)iters + met_V + met_Vdot + vrow_own + vconst + bcol[2] + ab0[1] + t0_own + Yrow[2] + Drow[1] + Ji[4])
   // ---------------- outputs: a_b = ab0 + sum B z ;  tau_(l,j) = Y_l[j] a_b + D_l[j] z_l + t0_l[j]
   double jic[3];
-#ifndef WBC_NO_LANEPARK
   {
     for (int k = 0; k < 6; k++) { Yrow[k] = pk.lget(LP_YROW + k); bcol[k] = pk.lget(LP_BCOL + k); ab0[k] = pk.lget(LP_AB0 + k); }
     for (int k = 0; k < 3; k++) { Drow[k] = pk.lget(LP_DROW + k); jic[k] = pk.lget(LP_JIC + k); rf[k] = pk.lget(LP_RF + k); }
@@ -1594,10 +1543,6 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     met_Vdot = pk.lget(LP_MET + 3); met_err = pk.lget(LP_MET + 4);
   }
   const double bcp[3] = {pk.lget(LP_BC + 0), pk.lget(LP_BC + 1), pk.lget(LP_BC + 2)};
-#else   // A/B build: everything stays in registers / AGPRs
-  for (int k = 0; k < 3; k++) jic[k] = pick3(sb, Ji[k], Ji[3 + k], Ji[6 + k]);
-  const double bcp[3] = {bc[0], bc[1], bc[2]};
-#endif
   const double z0 = qo.leg_bcast(z, 0), z1 = qo.leg_bcast(z, 1), z2 = qo.leg_bcast(z, 2);
   {
     double ab[6];
@@ -1605,6 +1550,11 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     double s = t0_own;
     for (int k = 0; k < 6; k++) s += Yrow[k] * ab[k];
     s += Drow[0] * z0 + Drow[1] * z1 + Drow[2] * z2;
+    // Nothing that is not a number leaves the tick (include/wbc.h "Malformed instances").  A NaN or an inf anywhere in what the law reads -- or finite inputs that
+    // overflow on the way -- has reached z and a_b by now, and through them the torque of every lane (0 x inf = NaN: no term drops out); the state-only metrics
+    // ride along in one more sum.  mu and the mass scale enter comparisons, which a NaN passes silently: they are tested themselves.  One 16-lane vote.
+    const bool bad = not_finite(s) | not_finite(met_V + met_Vdot + met_err);
+    if (qo.any16(bad)) status = ST_SINGULAR;
     if (colv) out_tau(m.act_inv[3 * l + sb], (status == ST_SINGULAR) ? 0.0 : s);
     // generalized accelerations of the QP solution (rows 4..21 of out_met); zeros with the zero torques of status 2
     const bool sing = (status == ST_SINGULAR);
@@ -1616,18 +1566,21 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     const double qdd = jic[0] * y[0] + jic[1] * y[1] + jic[2] * y[2];
     if (colv) out_met(4 + 6 + m.q_perm[3 * l + sb], sing ? 0.0 : qdd);
   }
+  const bool sing = (status == ST_SINGULAR);
+  const double errm = sing ? 0.0 : met_err;
   double res = 0.0;
   if (ct) res = fmax(fabs(z0) - mu * z2, fabs(z1) - mu * z2);
   res = fmax(0.0, qo.max16(res));
+  // a status-2 instance reports zeros throughout (what is not zero here is finite: the sentinel above has seen V, Vdot's state part and err)
   if (KIND == KIND_CLF) {
     // Vdot = 2 eta'PF eta + 2 eta'PG (J vd + Jdv - xdd_nom)   (clf_controller.py:230)
     const double vd = clf_c0 + clf_gab0 + qo.sum16(colv ? clf_g * z : 0.0);
-    out_met(0, met_V); out_met(1, met_err); out_met(2, 0.0); out_met(3, vd);
+    out_met(0, sing ? 0.0 : met_V); out_met(1, errm); out_met(2, 0.0); out_met(3, sing ? 0.0 : vd);
   } else if (KIND != KIND_ID) {
     met_Vdot += vconst + qo.sum16(colv ? vrow_own * z : 0.0);
-    out_met(0, met_V); out_met(1, met_err); out_met(2, 0.0); out_met(3, met_Vdot);
+    out_met(0, sing ? 0.0 : met_V); out_met(1, errm); out_met(2, 0.0); out_met(3, sing ? 0.0 : met_Vdot);
   } else {
-    out_met(0, 0.0); out_met(1, met_err); out_met(2, res); out_met(3, 0.0);
+    out_met(0, 0.0); out_met(1, errm); out_met(2, sing ? 0.0 : res); out_met(3, 0.0);
   }
   return status;
 }

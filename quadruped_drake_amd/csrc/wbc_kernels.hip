@@ -25,6 +25,7 @@ __device__ unsigned long long g_wbc_stamps[16 * 4096];
 #include "wbc_tick.hpp"
 #include "wbc_hex.hpp"
 #include "wbc_traj_dev.hpp"
+#include "wbc_device_guard.hpp"
 
 namespace {
 
@@ -104,24 +105,9 @@ __device__ __forceinline__ void stat_add_wave(StatsDev* stats, unsigned block, b
     atomicMax(reinterpret_cast<unsigned long long*>(w + 4 * STAT_SLOTS), (unsigned long long)__double_as_longlong(tm));
     atomicAdd(w + 5 * STAT_SLOTS, er);
   }
-#ifdef WBC_STATS_DISTINCT_MASKS
-  // contact masks: one atomic per DISTINCT mask of the wavefront (a stand: one, a trot: two), from the first robot that carries it
-  const unsigned row = (threadIdx.x >> 4) & 3u;
-  int cnt = 0;
-  bool first = true;
-#pragma unroll
-  for (unsigned j = 0; j < 4; j++) {
-    const unsigned mj = __builtin_amdgcn_readlane(mk, 16 * j);
-    const bool lj = __builtin_amdgcn_readlane(live ? 1 : 0, 16 * j) != 0;
-    const bool eq = lj && mj == mk;
-    cnt += eq ? 1 : 0;
-    first = first && !(eq && j < row);
-  }
-  if (live && first && (threadIdx.x & 15) == 0) atomicAdd(w + (6 + mk) * STAT_SLOTS, (double)cnt);
-#else
-  // contact masks: one lane-atomic per robot (one instruction for the four lead lanes)
+  // contact masks: one lane-atomic per robot (one instruction for the four lead lanes; one atomic per DISTINCT mask of the wavefront
+  // was measured: +1 % time for 30 KB less traffic, profiles/r04)
   if (live && (threadIdx.x & 15) == 0) atomicAdd(w + (6 + mk) * STAT_SLOTS, 1.0);
-#endif
 }
 
 __device__ __forceinline__ double wave_sum(double x) {
@@ -138,10 +124,7 @@ constexpr int MODEL_PAD_WORDS = 320;  // ModelC padded to 2.5 KB (multiple of 64
 // Replicas of the 2.5 KB model table in HBM, read by workgroup b % MODEL_REPLICAS: ONE copy is a hot line for a thousand wavefronts that start together (round 1: +18 us in the
 // first phase), one per workgroup is 640 KB of HBM reads per launch for 3 MB of inputs.  32 = four per XCD under the round-robin dispatch: same launch time as 256 (22.6 us; N = 32768
 // 150.6 against 151.8), HBM bytes per launch 5.33 -> 4.79 MB (profiles/r05/model_replicas.md).
-#ifndef WBC_MODEL_REPLICAS
-#define WBC_MODEL_REPLICAS 32
-#endif
-constexpr int MODEL_REPLICAS = WBC_MODEL_REPLICAS;
+constexpr int MODEL_REPLICAS = 32;
 static_assert(sizeof(wbc::ModelC) <= MODEL_PAD_WORDS * 8 && MODEL_PAD_WORDS % 64 == 0, "model padding");
 
 // ---------------------------------------------------------------- v4: 16 lanes (one DPP row) per robot
@@ -309,10 +292,8 @@ struct HexDev {
   }
 };
 
-#ifndef WBC_HEX_BLOCK
-#define WBC_HEX_BLOCK 64
-#endif
-constexpr int HEX_BLOCK = WBC_HEX_BLOCK;   // threads per workgroup of the 16-lane kernel (64 or 256)
+constexpr int HEX_BLOCK = 64;              // threads per workgroup of the 16-lane kernel: one wavefront (256 = one model copy per four wavefronts measured
+                                           // the same at N = 4096 and 3.5 % slower at N = 32768: a CU slot frees only when all four wavefronts are done)
 constexpr int HROBOTS = HEX_BLOCK / 16;    // robots per workgroup
 // robot-level park in LDS (wbc_hex.hpp): reads go through a laundered pointer so that the compiler
 // cannot forward the stored values (i.e. keep them in registers / spill them) yet the loads stay
@@ -335,25 +316,16 @@ struct ParkLds {
 // a 128-byte line are fetched by four different XCDs: FETCH_SIZE measured 4x the algorithmic input bytes (calibrated on the same
 // access shape: tools/micro/fetch_calib.hip, profiles/r02/fetch_calib.md).  Here workgroups b, b+8, b+16, b+24 -- the same XCD --
 // take the four segments of one line.  Placement is only a speed / traffic matter; any mapping is correct.
-#ifndef WBC_XCD_REMAP
-#define WBC_XCD_REMAP 1
-#endif
 __device__ __forceinline__ int hex_effective_block(int b, int nblocks) {
-#if WBC_XCD_REMAP
   const int full = nblocks & ~31;                 // groups of 32 workgroups = 8 XCDs x 4 segments; the ragged tail keeps the identity
   if (b >= full) return b;
   const int g = b >> 5, x = b & 7, y = (b >> 3) & 3;
   return (g << 5) + (x << 2) + y;
-#else
-  return b;
-#endif
 }
 
-#ifndef WBC_HEX_WAVES_PER_EU
-#define WBC_HEX_WAVES_PER_EU 1
-#endif
+// One wavefront per SIMD by design: 446 registers (two per SIMD by amdgpu_waves_per_eu(2): 996 B/lane of scratch, 2.3x slower, profiles/r02)
 template <int KIND, bool TB = false>
-__global__ void __launch_bounds__(HEX_BLOCK) __attribute__((amdgpu_waves_per_eu(WBC_HEX_WAVES_PER_EU)))
+__global__ void __launch_bounds__(HEX_BLOCK) __attribute__((amdgpu_waves_per_eu(1)))
 wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* __restrict__ pp, int n, int ld,
                const double* __restrict__ q, const double* __restrict__ v, const double* __restrict__ tg,
                const uint8_t* __restrict__ mask, const double* __restrict__ mu,
@@ -392,13 +364,12 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* __restric
   for (int j = 0; j < MPER; j++) t[j] = msrc[min(j * HEX_BLOCK + (int)threadIdx.x, MODEL_PAD_WORDS - 1)];
   {
     const int r0 = eb * HROBOTS;
-#if WBC_HEX_BLOCK == 64 && !defined(WBC_OLD_PROLOGUE)
     // Word j * 64 + t of the staged block is row 16 j + (t >> 2) of robot slot t & 3: the slot (hence the robot) is a per-lane constant and the row of
     // load j is 16 j + tr, so which array a load reads is known at compile time except for two of the six (rows 16 - 31: q | v, rows 32 - 47: v | targets).
     // Offsets are 32-bit (wbc_step rejects ld > WBC_MAX_LD = 2^23, so 54 rows x ld x 8 bytes stay below 4 GB): one multiply-add per address instead of the
     // two 64-bit multiply-adds, the selects between three base pointers and the 64-bit additions of the generic form (192 -> ~120 instructions before the
     // last load is issued; stamps: profiles/r05/prologue.md).
-    static_assert(NIN == 91 && HROBOTS == 4 && PER_LANE == 6, "prologue specialised to 91 rows x 4 robots per wavefront");
+    static_assert(HEX_BLOCK == 64 && NIN == 91 && HROBOTS == 4 && PER_LANE == 6, "prologue specialised to 91 rows x 4 robots per wavefront");
     const unsigned tr = threadIdx.x >> 2;
     const unsigned rob = (unsigned)min(r0 + (int)(threadIdx.x & 3), n - 1), uld = (unsigned)ld;
     tmp[0] = q[tr * uld + rob];
@@ -415,19 +386,9 @@ wbc_hex_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* __restric
     tmp[3] = tg[(11u + tr) * uld + rob];
     tmp[4] = tg[(27u + tr) * uld + rob];
     tmp[5] = tg[min(43u + tr, 53u) * uld + rob];                 // rows 80 - 90, the lanes beyond re-read the last row
-#else
-#pragma unroll
-    for (int j = 0; j < PER_LANE; j++) {
-      const int idx = min(j * HEX_BLOCK + (int)threadIdx.x, NIN * HROBOTS - 1);
-      const int row = idx / HROBOTS, sl = idx % HROBOTS;
-      const int rob = min(r0 + sl, n - 1);
-      const double* srow = row < 19 ? q + (size_t)row * ld : (row < 37 ? v + (size_t)(row - 19) * ld : tg + (size_t)(row - 37) * ld);
-      tmp[j] = srow[rob];
-    }
-#endif
   }
   WBC_STAMP(1);   // all loads issued
-  const unsigned mk = mask[ii] & 0xF;
+  const unsigned mk = mask[ii] & 0xF;   // (bits 4..7 are not read)
   // per-instance friction coefficient / mass scale, or the handle's mu / 1.0 read from the parameter block: one unconditional load each (the pointer
   // is selected, not the load skipped: two taken branches and a dependent scalar load less in every tick without domain randomisation)
   const double mu_in = *(mu ? mu + ii : &pp->mu), ms_in = *(ms ? ms + ii : &pp->one);
@@ -771,7 +732,7 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
   if (params) memcpy(&P, params, sizeof P);
   if (!(P.mu > 0) || !(P.eps2 > 0) || !(P.w_body > 0) || !(P.w_foot > 0) || !(P.tau_max > 0))
     return misuse("wbc_create: mu, eps2, w_body, w_foot and tau_max must be positive");
-  HIP_TRY(hipSetDevice(device));
+  WBC_ON_DEVICE(device, fail);
   wbc_handle h = new wbc_handle_s();
   h->kind = kind; h->max_batch = max_batch; h->device = device; h->flags = flags;
   h->variant = 0;
@@ -820,7 +781,7 @@ int wbc_create(const wbc_model* model, int kind, const wbc_params* params, int m
 
 int wbc_destroy(wbc_handle h) {
   if (!h) return 0;
-  (void)hipSetDevice(h->device);
+  wbc::DeviceGuard device_guard_(h->device);   // (a failure here leaves nothing to report to: the frees below are best effort)
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->zpend.active = false;   // a small-batch host-pointer tick that was never collected is ABANDONED: destroy writes nothing into caller-owned arrays
                              // (a caller on an error path may already have freed them); wbc_sync before wbc_destroy delivers it
@@ -860,7 +821,7 @@ static int launch(wbc_handle h, int n, int ld, const double* q, const double* v,
                   const uint8_t* mask, const double* mu, const double* ms, double* tau, double* met,
                   int32_t* status) {
   h->last_variant = 3;
-  StatsDev* d_stats = getenv("WBC_NO_STATS") ? nullptr : h->d_stats;  // diagnostic switch
+  StatsDev* d_stats = h->d_stats;
   dim3 grid((n + HROBOTS - 1) / HROBOTS);
 #ifdef WBC_DEV_ONLY   // diagnostic builds (tools/build_cuts.sh): ONE law instantiated, seconds to compile
   if (h->kind != WBC_DEV_ONLY || h->torque_box) return misuse("this diagnostic build carries one law only (WBC_DEV_ONLY)");
@@ -907,7 +868,7 @@ int wbc_step(wbc_handle h, int n, int ld, const double* q, const double* v, cons
   int rc = check_step_args(h, n, ld, q, v, targets, contact_mask, tau);
   if (rc) return rc;
   if (n == 0) return 0;
-  HIP_TRY(hipSetDevice(h->device));
+  WBC_ON_DEVICE(h->device, fail);
   if (!(h->flags & WBC_HOST_PTRS))
     return launch(h, n, ld, q, v, targets, contact_mask, mu, mass_scale, tau, metrics, status);
   rc = zc_finish(h);                    // a small-batch tick whose outputs were never collected: collect them first
@@ -948,7 +909,7 @@ int wbc_step(wbc_handle h, int n, int ld, const double* q, const double* v, cons
 
 int wbc_sync(wbc_handle h) {
   if (!h) return misuse("wbc_sync: null handle");
-  HIP_TRY(hipSetDevice(h->device));
+  WBC_ON_DEVICE(h->device, fail);
   HIP_TRY(hipStreamSynchronize(h->stream));
   return zc_finish(h);
 }
@@ -961,7 +922,7 @@ int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, cons
   if (rc) return rc;
   if (steps <= 0) return misuse("wbc_time_steps: steps must be positive");
   if (h->flags & WBC_HOST_PTRS) return misuse("wbc_time_steps: needs a WBC_DEVICE_PTRS handle (inputs resident in HBM)");
-  HIP_TRY(hipSetDevice(h->device));
+  WBC_ON_DEVICE(h->device, fail);
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
   for (int s = 0; s < steps; s++) {
     rc = launch(h, n, ld, q, v, targets, contact_mask, mu, mass_scale, tau, metrics, status);
@@ -976,7 +937,7 @@ int wbc_time_steps(wbc_handle h, int steps, int n, int ld, const double* q, cons
 int wbc_time_steps_result(wbc_handle h, float* ms_per_step) {
   if (!h || !ms_per_step) return misuse("wbc_time_steps_result: null argument");
   if (h->timed_steps <= 0) return misuse("wbc_time_steps_result: no wbc_time_steps call to report");
-  HIP_TRY(hipSetDevice(h->device));
+  WBC_ON_DEVICE(h->device, fail);
   HIP_TRY(hipEventSynchronize(h->ev1));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, h->ev0, h->ev1));
@@ -992,7 +953,7 @@ int wbc_time_steps_each(wbc_handle h, int steps, int n, int ld, const double* q,
   if (rc) return rc;
   if (steps <= 0 || !ms_each) return misuse("wbc_time_steps_each: steps must be positive and ms_each non-null");
   if (h->flags & WBC_HOST_PTRS) return misuse("wbc_time_steps_each: needs a WBC_DEVICE_PTRS handle (inputs resident in HBM)");
-  HIP_TRY(hipSetDevice(h->device));
+  WBC_ON_DEVICE(h->device, fail);
   while ((int)h->evs.size() < steps + 1) {
     hipEvent_t e;
     HIP_TRY(hipEventCreate(&e));
@@ -1011,7 +972,7 @@ int wbc_time_steps_each(wbc_handle h, int steps, int n, int ld, const double* q,
 
 int wbc_stats_get(wbc_handle h, wbc_stats* out) {
   if (!h || !out) return misuse("wbc_stats_get: null argument");
-  HIP_TRY(hipSetDevice(h->device));
+  WBC_ON_DEVICE(h->device, fail);
   StatsDev s;
   StatsDev* dst = nullptr;
   HIP_TRY(hipHostGetDevicePointer((void**)&dst, h->h_stats, 0));
@@ -1055,7 +1016,7 @@ int wbc_stats_reduce(const double* gathered, int world, wbc_stats* out) {
 
 int wbc_stats_reset(wbc_handle h) {
   if (!h) return misuse("wbc_stats_reset: null handle");
-  HIP_TRY(hipSetDevice(h->device));
+  WBC_ON_DEVICE(h->device, fail);
   HIP_TRY(hipMemsetAsync(h->d_stats, 0, sizeof(StatsDev) * (STAT_SLOTS + 1), h->stream));
   return 0;
 }
@@ -1081,7 +1042,7 @@ int wbc_integrate(wbc_handle h, int n, int ld, double dt, double* q, double* v, 
   if (n < 0 || (n > 0 && (ld < n || !q || !v || !vdot))) return misuse("wbc_integrate: bad arguments");
   if (h->flags & WBC_HOST_PTRS) return misuse("wbc_integrate: needs a WBC_DEVICE_PTRS handle");
   if (n == 0) return 0;
-  HIP_TRY(hipSetDevice(h->device));
+  WBC_ON_DEVICE(h->device, fail);
   hipLaunchKernelGGL(wbc_integrate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, ld, dt, q, v, vdot);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1096,7 +1057,7 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
   if (rc) return rc;
   if (h->flags & WBC_HOST_PTRS) return misuse("wbc_rollout: needs a WBC_DEVICE_PTRS handle");
   if (steps == 0 || n == 0) return 0;
-  HIP_TRY(hipSetDevice(h->device));
+  WBC_ON_DEVICE(h->device, fail);
 #ifdef WBC_DEV_ONLY
   return misuse("wbc_rollout: not part of a WBC_DEV_ONLY diagnostic build");
 #else
@@ -1105,7 +1066,7 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
     wbc::TrajDev T;
     if (wbc_traj_raw_(traj, &T)) return misuse("wbc_rollout: bad trajectory handle");
     h->last_variant = 3;
-    StatsDev* d_stats = getenv("WBC_NO_STATS") ? nullptr : h->d_stats;
+    StatsDev* d_stats = h->d_stats;
     dim3 grid((n + HROBOTS - 1) / HROBOTS);
 #define WBC_RO_ARGS grid, dim3(HEX_BLOCK), 0, h->stream, h->d_model, h->d_params, n, ld, steps, dt, T, q, v, time, targets, \
                     contact_mask, mu, mass_scale, tau, metrics, status, d_stats, vdot
@@ -1145,6 +1106,7 @@ int wbc_variant_for(wbc_handle h, int n) {
 
 int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads) {
   if (!h) return misuse("wbc_kernel_info: null handle");
+  WBC_ON_DEVICE(h->device, fail);
   hipFuncAttributes a;
   const void* fn;
 #ifdef WBC_DEV_ONLY
@@ -1169,6 +1131,7 @@ int wbc_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_by
 
 int wbc_rollout_kernel_info(wbc_handle h, int* num_vgpr, int* scratch_bytes, int* lds_bytes, int* block_threads) {
   if (!h) return misuse("wbc_rollout_kernel_info: null handle");
+  WBC_ON_DEVICE(h->device, fail);
   hipFuncAttributes a;
   const void* fn;
 #ifdef WBC_DEV_ONLY

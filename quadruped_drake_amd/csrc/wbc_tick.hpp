@@ -80,7 +80,7 @@ namespace wbc {
 // instead of the IEEE division / sqrt expansions (~15 instructions each with scaling and fix-up, which
 // only matter for denormal or huge inputs).  Accurate to ~1 ulp; 0, inf and NaN propagate to inf/NaN
 // results that every caller discards through a select.  Host: the exact operations.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(WBC_NO_FAST_MATH)
+#if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ double fast_rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);
   double e = __builtin_fma(-x, r, 1.0);
@@ -148,6 +148,11 @@ enum { ST_OK = 0, ST_ITER = 1, ST_SINGULAR = 2, ST_ILLCOND = 3 };
 // both solvers reporting success -- there is no trustworthy answer.  A tick of these laws with |sin(knee)| < 1e-4 on any leg
 // is therefore solved as usual (torques and accelerations written) but REPORTED: status 3 "ill-conditioned".
 constexpr double KNEE_ILLCOND = 1e-4;
+// Malformed instances (include/wbc.h): the tick reports -- status 2, zero torques and accelerations -- what it cannot answer with finite numbers, where the
+// reference would assert (inverse_dynamics_controller.py:224) or hand NaN on.  The test is on the OUTPUT side (hex_tick's last stage): every value the
+// law reads reaches the torques through arithmetic, so one look at them finds a NaN / inf input, and an overflow on the way, at a dozen instructions.
+// !(|x| < inf) is true for NaN and for +-inf.
+WBC_HD bool not_finite(double x) { return !(fabs(x) < __builtin_huge_val()); }
 
 struct LinkC {
   double off[3];  // joint origin in the parent link frame

@@ -11,6 +11,7 @@
 #include "../../include/wbc.h"
 #include "../../include/wbc_extras.h"
 #include "wbc_traj_dev.hpp"
+#include "wbc_device_guard.hpp"
 
 // the one thread-local message buffer behind wbc_last_error() (defined in wbc_kernels.hip)
 extern "C" void wbc_set_error_(const char* msg);
@@ -168,7 +169,7 @@ int wbc_robot_states_unpack(int device, void* hip_stream, int n, int ld, const u
   if (n < 0 || ld < n || (n > 0 && (!msgs || !q || !v))) return tmisuse("wbc_robot_states_unpack: bad argument");
   if (((uintptr_t)msgs & 3u) != 0) return tmisuse("wbc_robot_states_unpack: msgs must be 4-byte aligned");
   if (n == 0) return 0;
-  HIP_TRY(hipSetDevice(device));
+  WBC_ON_DEVICE(device, tfail);
   hipLaunchKernelGGL(robot_states_unpack_kernel, dim3((n + 255) / 256, 37), dim3(256), 0, (hipStream_t)hip_stream, n, ld,
                      reinterpret_cast<const uint32_t*>(msgs), q, v, ok);
   HIP_TRY(hipGetLastError());
@@ -190,7 +191,7 @@ int wbc_robot_controls_pack(int device, void* hip_stream, int n, int ld, const d
     src.k[jd] = k;
   }
   if (n == 0) return 0;
-  HIP_TRY(hipSetDevice(device));
+  WBC_ON_DEVICE(device, tfail);
   hipLaunchKernelGGL(robot_controls_pack_kernel, dim3((n + 255) / 256, kRsWords), dim3(256), 0, (hipStream_t)hip_stream, n, ld,
                      tau, src, reinterpret_cast<uint32_t*>(msgs));
   HIP_TRY(hipGetLastError());
@@ -214,7 +215,7 @@ int wbc_pd_step(int device, void* hip_stream, int n, int ld, const double* q, co
     a.qn[k] = q_nom19 ? q_nom19[7 + jd] : kNominal[jd % 3];
   }
   if (n == 0) return 0;
-  HIP_TRY(hipSetDevice(device));
+  WBC_ON_DEVICE(device, tfail);
   hipLaunchKernelGGL(pd_step_kernel, dim3((n + 255) / 256, 12), dim3(256), 0, (hipStream_t)hip_stream, n, ld, q, v, a, kp, kd, u_max, tau);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -243,7 +244,7 @@ int wbc_traj_create(int device, int K, const double* timestamps, const double* t
     return tmisuse("wbc_traj_create: bad argument");
   for (int i = 1; i < K; i++)
     if (!(timestamps[i] >= timestamps[i - 1])) return tmisuse("wbc_traj_create: timestamps must be non-decreasing");
-  HIP_TRY(hipSetDevice(device));
+  WBC_ON_DEVICE(device, tfail);
   wbc_traj t = new wbc_traj_s();
   memset(t, 0, sizeof *t);
   t->device = device; t->K = K; t->wait_time = wait_time; t->standing_mask = standing_mask;
@@ -270,7 +271,7 @@ int wbc_traj_create(int device, int K, const double* timestamps, const double* t
 
 int wbc_traj_destroy(wbc_traj t) {
   if (!t) return 0;
-  (void)hipSetDevice(t->device);
+  wbc::DeviceGuard device_guard_(t->device);
   (void)hipFree(t->d_ts); (void)hipFree(t->d_table); (void)hipFree(t->d_masks); (void)hipFree(t->d_standing);
   delete t;
   return 0;
@@ -280,7 +281,7 @@ int wbc_traj_lookup(wbc_traj t, void* hip_stream, int n, int ld, const double* t
                     uint8_t* contact_mask) {
   if (!t || n < 0 || (n > 0 && (ld < n || !time || !targets || !contact_mask))) return tmisuse("wbc_traj_lookup: bad argument");
   if (n == 0) return 0;
-  HIP_TRY(hipSetDevice(t->device));
+  WBC_ON_DEVICE(t->device, tfail);
   wbc::TrajDev T{t->K, t->wait_time, t->d_ts, t->d_table, t->d_masks, t->d_standing, t->standing_mask};
   hipLaunchKernelGGL(traj_lookup_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, n, ld, T, time,
                      targets, contact_mask);

@@ -27,6 +27,28 @@ def lib():
     return _LIB
 
 
+def build_variant(tmp_path, name, flags, compiler="g++"):
+    """A host instantiation of the kernel headers with the CLOSED alternatives available again (the -DWBC_... switches that round 6 removed from
+    the product source: tools/lab/patches/closed_switches.patch re-introduces them): the sources are copied to `tmp_path`, patched there and
+    compiled with `flags`.  Without flags the patched tree is the product's code, so a comparison against the default build is a comparison
+    against what ships.  Returns the loaded library."""
+    import shutil
+    tree = os.path.join(str(tmp_path), "tree_" + name)
+    for sub in ("quadruped_drake_amd/csrc", "tools", "include"):
+        os.makedirs(os.path.join(tree, sub), exist_ok=True)
+    for f in os.listdir(os.path.join(_ROOT, "quadruped_drake_amd", "csrc")):
+        shutil.copy(os.path.join(_ROOT, "quadruped_drake_amd", "csrc", f), os.path.join(tree, "quadruped_drake_amd", "csrc", f))
+    for f in ("host_tick.cpp", "wbc_scalar_tick.hpp"):
+        shutil.copy(os.path.join(_ROOT, "tools", f), os.path.join(tree, "tools", f))
+    for f in os.listdir(os.path.join(_ROOT, "include")):
+        shutil.copy(os.path.join(_ROOT, "include", f), os.path.join(tree, "include", f))
+    subprocess.check_call(["patch", "-p1", "-s", "--no-backup-if-mismatch", "-i", os.path.join(_ROOT, "tools", "lab", "patches", "closed_switches.patch")], cwd=tree)
+    so = os.path.join(str(tmp_path), name)
+    subprocess.check_call([compiler, "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off"] + list(flags) +
+                          ["-o", so, os.path.join(tree, "tools", "host_tick.cpp")])
+    return C.CDLL(so)
+
+
 def _p(a):
     return a.ctypes.data_as(_dp) if a is not None else None
 

@@ -14,11 +14,12 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-4         # the north-star bar: odd states (all 16 masks, torque boxes on stands, permuted plants, singular sweeps)
 TOL_TROT = 1e-6    # configs 3, 4, 5 (2-contact trots), every law: measured <= 2e-7 over 33 M instances
-TOL_STAND = 1e-5   # config 2 (4-contact stands far outside their pyramids): measured <= 6e-7 (ID, MPTC) / 4.2e-6 (PC) over 4 M
+TOL_STAND = 2e-6   # config 2 (4-contact stands far outside their pyramids), ID and MPTC: measured <= 8e-7 over 4 M instances per line (profiles/r05/soak.md)
+TOL_STAND_PC = 1e-5   # the PC / CLF stands: 4.2e-6 measured, where the double-precision oracle itself is 4e-6 from its extended-precision twin
 
 
-def tol_for(cfg):
-    return TOL_STAND if cfg == 2 else TOL_TROT
+def tol_for(cfg, kind="id"):
+    return (TOL_STAND_PC if kind in ("pc", "clf") else TOL_STAND) if cfg == 2 else TOL_TROT
 
 
 GOLD = sorted(f for f in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
@@ -73,7 +74,7 @@ def test_gpu_matches_golden_vectors(path):
     tau, met, st, _ = gpu_step(g["kind"], g["model"], g["q"], g["v"], g["targets"], g["mask"], g["mu"], g["mass_scale"])
     assert np.array_equal(st, g["status"])
     name = os.path.basename(path)
-    tol = TOL_STAND if name.startswith(("cfg2", "masks16")) else TOL_TROT      # masks16: every contact pattern, stands included
+    tol = tol_for(2, g["kind"]) if name.startswith(("cfg2", "masks16")) else TOL_TROT      # masks16: every contact pattern, stands included
     assert rel_err(tau, g["tau"]).max() < tol, rel_err(tau, g["tau"]).max()
     assert np.allclose(met, g["metrics"], rtol=1e-5, atol=1e-6)
 
@@ -89,7 +90,7 @@ def test_gpu_matches_oracle_on_seeded_batches(cfg, kind, n):
     tau_o, met_o, st_o = orc.step_batch(kind, m, p, b["q"], b["v"], b["targets"], b["mask"], b["mu"], b["mass_scale"])
     assert (st == 0).all() and (st_o == 0).all()
     r = rel_err(tau, tau_o)
-    assert r.max() < tol_for(cfg), r.max()
+    assert r.max() < tol_for(cfg, kind), r.max()
     assert np.median(r) < 1e-9
     assert np.allclose(met, met_o, rtol=1e-5, atol=1e-6)
     # device-side end-of-rollout statistics agree with the outputs
@@ -434,7 +435,7 @@ def test_full_size_oracle_parity(cfg, kind, n):
                                         b["mu"], b["mass_scale"], nthreads=cores)
     assert (st == 0).all() and (st_o == 0).all()
     r = rel_err(tau, tau_o)
-    assert r.max() < tol_for(cfg), (r.max(), int(r.argmax()))
+    assert r.max() < tol_for(cfg, kind), (r.max(), int(r.argmax()))
     assert np.median(r) < 1e-9
     assert np.allclose(met, met_o, rtol=1e-5, atol=1e-6)
     assert stats["ticks"] == n
@@ -469,7 +470,7 @@ def test_saturated_stands_at_depth(kind):
         worst = max(worst, float(r.max())); above6 += int((r > 1e-6).sum()); above5 += int((r > 1e-5).sum())
     ctrl.close()
     assert mism == 0
-    assert worst < TOL_STAND and above5 == 0, (worst, above6, above5)
+    assert worst < tol_for(2, kind) and above5 == 0, (worst, above6, above5)
     assert above6 <= 8, (worst, above6)          # measured: 0 (ID, MPTC), 2 (PC: the double-precision oracle's own two outliers)
 
 

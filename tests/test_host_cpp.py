@@ -13,6 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "examples", "wbc_host")
 
 
+def _need_exe():
+    """The example is built best-effort (build_examples): only the example itself, never the whole build(), and a box without the RCCL development
+    files skips these tests instead of failing them."""
+    if not os.path.exists(EXE):
+        import __graft_entry__ as g
+        if not (os.path.exists(g.HIP_SO) and g.build_examples()):
+            pytest.skip("examples/wbc_host is not built here (no libwbc_hip.so yet, or no RCCL development files)")
+
+
 def test_batch_dump_layout(tmp_path):
     """workloads.dump_batch writes what examples/wbc_host.cpp's load_batch reads: header, wbc_model, rows, padded mask, mu / mass scale."""
     from quadruped_drake_amd import workloads
@@ -39,9 +48,7 @@ def test_batch_dump_layout(tmp_path):
 
 def test_host_binary_is_built_and_links_the_abi_and_rccl_only():
     """build() compiles it against include/wbc.h, libwbc_hip.so and librccl; no Python, no torch in its process."""
-    if not os.path.exists(EXE):
-        import __graft_entry__ as g
-        g.build()
+    _need_exe()
     out = subprocess.run(["ldd", EXE], capture_output=True, text=True, check=True).stdout
     assert "libwbc_hip.so" in out and "librccl" in out and "libamdhip64" in out
     assert "torch" not in out and "python" not in out.lower()
@@ -57,9 +64,7 @@ def test_host_binary_rejects_a_bad_batch_file_and_has_no_cpu_path(tmp_path):
     """The batch file is parsed before any GPU call: a truncated / foreign file is an error message and exit code 1, and a good file without a
     GPU ends with "no GPU visible" -- the C++ host has no CPU fallback either."""
     from quadruped_drake_amd import workloads
-    if not os.path.exists(EXE):
-        import __graft_entry__ as g
-        g.build()
+    _need_exe()
     bad = tmp_path / "bad.bin"; bad.write_bytes(b"NOTABATCH" + bytes(64))
     r = subprocess.run([EXE, "--batch", str(bad)], capture_output=True, text=True)
     assert r.returncode == 1 and "bad batch file" in r.stderr

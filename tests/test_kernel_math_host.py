@@ -170,15 +170,52 @@ def test_nearly_straight_knee_is_reported_as_ill_conditioned():
         assert (st == 0).all() and (st_o == 0).all() and rel_err(tau, tau_o).max() < 1e-5
 
 
-def test_nan_state_is_reported_with_zero_outputs():
-    """A non-finite state cannot be solved: status 2, zero torques and zero accelerations (never NaN outputs)."""
-    b = workloads.make_batch(3, n=4)
-    t = orc.load_model_json("mini_cheetah")
-    q = b["q"].copy(); q[7 + 4, 1] = np.nan
-    for kind in ("id", "mptc"):
-        tau, met, st, it, vd = ht.run(kind, t["flat"], q, b["v"], b["targets"], b["mask"], hexv=True, want_vdot=True)
-        assert st.tolist() == [0, 2, 0, 0]
-        assert (tau[:, 1] == 0).all() and (vd[:, 1] == 0).all() and np.isfinite(tau).all() and np.isfinite(vd).all()
+@pytest.mark.parametrize("kind", ["id", "mptc", "pc", "clf"])
+def test_malformed_instances_are_reported_with_zero_outputs(kind):
+    """include/wbc.h "Malformed instances" on the host instantiation of the kernel headers and on the oracle's mirror of the convention: every
+    case of tests/poisons.py in one batch (half trot states, half saturated stands).  A malformed instance: status 2, zero torques and
+    accelerations, finite metrics, on both sides; an odd-looking legal one (non-unit quaternion, contact-mask bits above 0xF): status 0 and the
+    clean instance's outputs; nothing non-finite anywhere; every untouched instance keeps its bits."""
+    from poisons import POISONS, copy_batch, expected_status
+    names = list(POISONS)
+    n = 2 * len(names) + 8
+    bt, bs = workloads.make_batch(5, n=n), workloads.make_batch(2, n=n)
+    base = copy_batch(bt, n)
+    half = np.arange(n) >= n // 2
+    for k in ("q", "v", "targets"):
+        base[k][:, half] = bs[k][:, half]
+    base["mask"][half] = 0xF
+    bad = copy_batch(base, n)
+    where = {}
+    for j, name in enumerate(names):
+        for i in (j, n // 2 + j):              # once on a trot state, once on a stand
+            POISONS[name][0](bad, i)
+            where[i] = name
+    flat = orc.load_model_json("mini_cheetah")["flat"]
+    m, p = orc.model("mini_cheetah"), orc.params(kind)
+    run = lambda b: ht.run(kind, flat, b["q"], b["v"], b["targets"], b["mask"], mu=b["mu"], mass_scale=b["mass_scale"], hexv=True, want_vdot=True)
+    tau0, met0, st0, it0, vd0 = run(base)
+    tau, met, st, it, vd = run(bad)
+    tau_o, met_o, st_o = orc.step_batch(kind, m, p, bad["q"], bad["v"], bad["targets"], bad["mask"], bad["mu"], bad["mass_scale"])
+    assert np.isfinite(tau).all() and np.isfinite(met).all() and np.isfinite(vd).all() and np.isfinite(tau_o).all() and np.isfinite(met_o).all()
+    clean = np.array([i not in where for i in range(n)])
+    assert (st0 == 0).all()
+    for a, b in ((tau, tau0), (met, met0), (vd, vd0)):
+        assert np.array_equal(a[:, clean], b[:, clean])
+    assert np.array_equal(st[clean], st0[clean]) and np.array_equal(it[clean], it0[clean])
+    for i, name in where.items():
+        want = expected_status(name, bad["mask"][i])
+        assert st[i] == st_o[i], (name, i, st[i], st_o[i])
+        if want is not None:
+            assert st[i] == want, (name, i, st[i])
+        if st[i] == 2:
+            assert (tau[:, i] == 0).all() and (vd[:, i] == 0).all() and (tau_o[:, i] == 0).all() and (it[i] == 0 or want is None), name
+            assert met[2, i] == 0 and met[3, i] == 0, name
+        elif want == 0:
+            # a legal input: the clean instance's outputs (the quaternion's scale cancels in 2 / |q|^2 up to rounding; mask bits above 0xF are not read)
+            tol = 0.0 if name in ("mask_high_bits", "nan_foot_target", "inf_foot_rate_tgt") else 1e-6     # (a saturated stand amplifies the last-bit change of R by 1e4: measured 1e-8)
+            assert np.abs(tau[:, i] - tau0[:, i]).max() <= tol * np.abs(tau0[:, i]).max(), name
+            assert rel_err(tau[:, i:i + 1], tau_o[:, i:i + 1]).max() < 1e-5, name
 
 
 def test_pc_enforces_passivity_where_mptc_does_not():
@@ -224,10 +261,7 @@ def test_evaluation_after_a_drop_and_graded_pivots_on_host(tmp_path):
     dp = C.POINTER(C.c_double)
 
     def build(flags, name):
-        so = str(tmp_path / name)
-        subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off"] + flags +
-                              ["-o", so, os.path.join(root, "tools", "host_tick.cpp")])
-        return C.CDLL(so)
+        return ht.build_variant(tmp_path, name, flags)
 
     def run(L, kind, b):
         n = b["q"].shape[1]
@@ -266,10 +300,7 @@ def test_swing_row_compaction_changes_no_bit(tmp_path):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    so = str(tmp_path / "libhost_tick_nocompact.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", "-DWBC_NO_SWING_COMPACT",
-                           "-o", so, os.path.join(root, "tools", "host_tick.cpp")])
-    L = C.CDLL(so)
+    L = ht.build_variant(tmp_path, "libhost_tick_nocompact.so", ["-DWBC_NO_SWING_COMPACT"])
     dp = C.POINTER(C.c_double)
     n = 64
     b = workloads.make_batch(3, n=n)
@@ -327,10 +358,7 @@ def test_apex_rule_and_deterministic_pick_on_host(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dp = C.POINTER(C.c_double)
-    so = str(tmp_path / "libhost_noapex.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", "-DWBC_NO_APEX_RULE", "-DWBC_PICK_BITS=5",
-                           "-o", so, os.path.join(root, "tools", "host_tick.cpp")])
-    old = C.CDLL(so)
+    old = ht.build_variant(tmp_path, "libhost_noapex.so", ["-DWBC_NO_APEX_RULE", "-DWBC_PICK_BITS=5"])
 
     def run_old(kind, b):
         n = b["q"].shape[1]
@@ -367,10 +395,7 @@ def test_pick_rule_by_contact_count_on_the_dense_row_laws(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dp = C.POINTER(C.c_double)
-    so = str(tmp_path / "libhost_nohybrid.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", "-DWBC_HYBRID_PICK=0",
-                           "-o", so, os.path.join(root, "tools", "host_tick.cpp")])
-    old = C.CDLL(so)
+    old = ht.build_variant(tmp_path, "libhost_nohybrid.so", ["-DWBC_HYBRID_PICK=0"])
 
     def run_old(kind, b):
         n = b["q"].shape[1]
@@ -409,10 +434,7 @@ def test_clf_row_built_lazily(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dp = C.POINTER(C.c_double)
-    so = str(tmp_path / "libhost_nolazy.so")
-    subprocess.check_call(["g++", "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", "-DWBC_LAZY_DENSE=0",
-                           "-o", so, os.path.join(root, "tools", "host_tick.cpp")])
-    old = C.CDLL(so)
+    old = ht.build_variant(tmp_path, "libhost_nolazy.so", ["-DWBC_LAZY_DENSE=0"])
 
     def run_old(b, tg):
         n = b["q"].shape[1]
@@ -489,3 +511,26 @@ def test_no_unwritten_storage_feeds_the_arithmetic(tmp_path):
         assert np.array_equal(tau, tau_p) and np.array_equal(met, met_p), (cfg, kind, tmax)
         if cfg == 2:
             assert it.mean() > 8          # drop-heavy: the evaluation after a drop runs
+
+
+def test_closed_switches_patch_applies_and_is_neutral(tmp_path):
+    """tools/lab/patches/closed_switches.patch puts the compile-time switches of rounds 1-5 (alternatives that were measured and closed; removed from
+    the product source in round 6) back into a copy of the headers.  It must apply to the current tree, and without any -D flag the patched tree must
+    still be the product's arithmetic: same bits as the ordinary host build on a stand and a trot of every law."""
+    import ctypes as C
+    L = ht.build_variant(tmp_path, "libhost_patched.so", [])
+    dp = C.POINTER(C.c_double)
+    n = 48
+    for cfg in (2, 3):
+        b = workloads.make_batch(cfg, n=n)
+        t = orc.load_model_json(b["model"])
+        q, v, tg = (np.ascontiguousarray(b[x]) for x in ("q", "v", "targets"))
+        flat = np.ascontiguousarray(t["flat"], dtype=np.float64)
+        for kind, k in (("id", 0), ("mptc", 1), ("pc", 2), ("clf", 3)):
+            tau = np.zeros((12, n)); met = np.zeros((4, n)); st = np.zeros(n, np.int32); it = np.zeros(n, np.int32)
+            rc = L.host_hex_batch(k, flat.ctypes.data_as(dp), None, None, None, n, n, q.ctypes.data_as(dp), v.ctypes.data_as(dp), tg.ctypes.data_as(dp),
+                                  b["mask"].ctypes.data_as(C.POINTER(C.c_ubyte)), None, None, tau.ctypes.data_as(dp), met.ctypes.data_as(dp),
+                                  st.ctypes.data_as(C.POINTER(C.c_int)), it.ctypes.data_as(C.POINTER(C.c_int)))
+            assert rc == 0
+            tau_g, met_g, st_g, it_g = ht.run(kind, t["flat"], b["q"], b["v"], b["targets"], b["mask"], hexv=True)
+            assert np.array_equal(tau, tau_g) and np.array_equal(met, met_g) and np.array_equal(st, st_g) and np.array_equal(it, it_g), (cfg, kind)

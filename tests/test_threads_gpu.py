@@ -113,3 +113,55 @@ def test_last_error_is_thread_local():
     assert seen["integrate"][0] < 0 and b"wbc_integrate" in seen["integrate"][1]
     assert L.wbc_last_error() == main_msg
     ctrl.close()
+
+
+@pytest.mark.gpu
+def test_calls_leave_the_callers_current_device_alone():
+    """include/wbc.h "Current device": every wbc_* call runs on its handle's device and restores the calling thread's current HIP device (round 5's
+    calls left it on the handle's: a second handle on another GPU, or torch on the same thread, was silently moved).  Two handles are stepped on ONE
+    thread and hipGetDevice is read around every call.  With two or more GPUs visible the handles sit on different devices and the thread's current
+    device is a third choice; on a one-GPU box the assertion is the same (device 0 before and after) and the calls are checked to have gone through
+    hipGetDevice / hipSetDevice at all by the library exporting nothing that bypasses the guard (every GPU entry point is exercised here)."""
+    import torch
+    from quadruped_drake_amd import _lib, MPTCController, IDController
+    from quadruped_drake_amd.trajectory import TrunkTrajectory
+    hip = C.CDLL("libamdhip64.so")
+    ndev = torch.cuda.device_count()
+    dev_a, dev_b = 0, (1 if ndev >= 2 else 0)
+    home = (ndev - 1) if ndev >= 2 else 0                       # the device the thread calls "current"
+
+    def current():
+        d = C.c_int(-1)
+        assert hip.hipGetDevice(C.byref(d)) == 0
+        return d.value
+
+    assert hip.hipSetDevice(home) == 0
+    n = 32
+    q0, v0, tg, mk = _start(n, 3)
+    ctrls = [(MPTCController(max_batch=n, device=dev_a), dev_a), (IDController(max_batch=n, device=dev_b), dev_b)]
+    assert current() == home
+    for ctrl, d in ctrls:
+        with torch.cuda.device(d):
+            dev = "cuda:%d" % d
+            q = torch.tensor(q0, device=dev); v = torch.tensor(v0, device=dev); t = torch.tensor(tg, device=dev); m = torch.tensor(mk, device=dev)
+            tm = torch.zeros(n, dtype=torch.float64, device=dev)
+            vd = torch.zeros((18, n), dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+        assert hip.hipSetDevice(home) == 0
+        calls = [lambda: ctrl.step(q, v, t, m), lambda: ctrl.sync(), lambda: ctrl.set_vdot_output(vd), lambda: ctrl.step(q, v, t, m),
+                 lambda: ctrl.integrate(q, v, vd, 1e-3), lambda: ctrl.stats(), lambda: ctrl.stats_reset(), lambda: ctrl.kernel_info(),
+                 lambda: ctrl.kernel_info(rollout=True), lambda: ctrl.time_steps(3, q, v, t, m), lambda: ctrl.sync()]
+        for k, call in enumerate(calls):
+            call()
+            assert current() == home, (d, k)
+        ts, tgt, masks = np.arange(8) * 1e-3, np.tile(tg[:, 0], (8, 1)), np.full(8, 0b1111, np.uint8)
+        traj = TrunkTrajectory(ts, tgt, masks, wait_time=0.0, device=d, standing_targets=tg[:, 0], standing_mask=0b1111)
+        assert current() == home
+        ctrl.rollout(traj, 5, 1e-3, q, v, tm); ctrl.sync()
+        assert current() == home
+        traj.close()
+        assert current() == home
+    for ctrl, d in ctrls:
+        ctrl.close()
+        assert current() == home
+    assert hip.hipSetDevice(0) == 0

@@ -307,8 +307,8 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
     int it = 0, st;
     const double mui = a.mu ? a.mu[i] : P.mu, msi = a.ms ? a.ms[i] : 1.0;
     const bool tb = P.tau_max < 1e300;
-#define HEX_RUN(K) (tb ? wbc::hex_tick<HexHost, K, true>(m, P, qo, in, a.mask[i], mui, msi, pk[h], ot, om, &it) \
-                       : wbc::hex_tick<HexHost, K, false>(m, P, qo, in, a.mask[i], mui, msi, pk[h], ot, om, &it))
+#define HEX_RUN(K) (tb ? wbc::hex_tick<HexHost, K, true>(m, P, qo, in, a.mask[i] & 0xFu, mui, msi, pk[h], ot, om, &it) \
+                       : wbc::hex_tick<HexHost, K, false>(m, P, qo, in, a.mask[i] & 0xFu, mui, msi, pk[h], ot, om, &it))
     if (a.kind == wbc::KIND_ID) st = HEX_RUN(wbc::KIND_ID);
     else if (a.kind == wbc::KIND_PC) st = HEX_RUN(wbc::KIND_PC);
     else if (a.kind == wbc::KIND_CLF) st = HEX_RUN(wbc::KIND_CLF);
