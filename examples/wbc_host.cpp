@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
@@ -124,36 +125,73 @@ struct RankResult {
   int num_vgpr = 0, scratch = 0, lds = 0;
 };
 
-#define HOST_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { res->err = std::string(#x ": ") + hipGetErrorString(e_); bar->abort(); return; } } while (0)
-#define HOST_WBC(x) do { if ((x) != 0) { res->err = std::string(#x ": ") + wbc_last_error(); bar->abort(); return; } } while (0)
-#define HOST_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) { res->err = std::string(#x ": ") + ncclGetErrorString(r_); bar->abort(); return; } } while (0)
+// What the GPU threads share besides the barrier: the communicators (so that a rank that fails can release peers that are already inside, or about to
+// enter, the collective: ncclCommAbort makes a pending ncclAllGather / stream wait return instead of waiting for a rank that will never arrive).
+struct Team {
+  Barrier bar;
+  std::vector<ncclComm_t>* comms;
+  std::atomic<bool> failed{false};
+  std::once_flag abort_once;
+  explicit Team(int n, std::vector<ncclComm_t>* c) : bar(n), comms(c) {}
+  void fail() {
+    failed.store(true);
+    bar.abort();
+    std::call_once(abort_once, [&] { for (ncclComm_t c : *comms) (void)ncclCommAbort(c); });
+  }
+};
 
-void rank_main(int rank, int world, const Options& o, const Batch& b, ncclComm_t comm, Barrier* bar, RankResult* res) {
+// Everything a rank allocates, released on every way out of rank_main (the early returns of the error macros included).
+struct RankResources {
+  wbc_handle h = nullptr;
+  hipStream_t cs = nullptr;
+  std::vector<void*> bufs;
+  template <class T> hipError_t alloc(T** p, size_t bytes) {
+    const hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes);
+    if (e == hipSuccess) bufs.push_back(*p);
+    return e;
+  }
+  ~RankResources() {
+    if (cs) (void)hipStreamDestroy(cs);
+    for (void* p : bufs) (void)hipFree(p);
+    if (h) (void)wbc_destroy(h);
+  }
+};
+
+#define HOST_FAIL(msg) do { res->err = (msg); team->fail(); return; } while (0)
+#define HOST_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) HOST_FAIL(std::string(#x ": ") + hipGetErrorString(e_)); } while (0)
+#define HOST_WBC(x) do { if ((x) != 0) HOST_FAIL(std::string(#x ": ") + wbc_last_error()); } while (0)
+#define HOST_NCCL(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) HOST_FAIL(std::string(#x ": ") + ncclGetErrorString(r_)); } while (0)
+// a peer has failed: do not enter (or go on after) a collective it will never join
+#define HOST_PEERS_OK() do { if (team->failed.load()) { res->err = "stopped: another rank failed"; return; } } while (0)
+
+void rank_main(int rank, int world, const Options& o, const Batch& b, ncclComm_t comm, Team* team, RankResult* res) {
+  Barrier* bar = &team->bar;
   int lo, hi;
   shard_range(b.n, rank, world, &lo, &hi);
   const int n = hi - lo, ldh = b.n;
   res->n = n;
   HOST_HIP(hipSetDevice(rank));
-  wbc_handle h = nullptr;
+  RankResources R;
+  wbc_handle& h = R.h;
   HOST_WBC(wbc_create(&b.model, b.kind, nullptr, n, rank, WBC_DEVICE_PTRS, &h));
   double *q, *v, *tg, *mu = nullptr, *ms = nullptr, *tau, *met, *d_send, *d_recv;
   uint8_t* mask;
   int32_t* status;
   const size_t nb = (size_t)n * 8;
-  HOST_HIP(hipMalloc(&q, 19 * nb)); HOST_HIP(hipMalloc(&v, 18 * nb)); HOST_HIP(hipMalloc(&tg, 54 * nb));
-  HOST_HIP(hipMalloc(&mask, n)); HOST_HIP(hipMalloc(&tau, 12 * nb)); HOST_HIP(hipMalloc(&met, 4 * nb)); HOST_HIP(hipMalloc(&status, (size_t)n * 4));
-  HOST_HIP(hipMalloc(&d_send, WBC_NSTAT * 8)); HOST_HIP(hipMalloc(&d_recv, (size_t)world * WBC_NSTAT * 8));
+  HOST_HIP(R.alloc(&q, 19 * nb)); HOST_HIP(R.alloc(&v, 18 * nb)); HOST_HIP(R.alloc(&tg, 54 * nb));
+  HOST_HIP(R.alloc(&mask, n)); HOST_HIP(R.alloc(&tau, 12 * nb)); HOST_HIP(R.alloc(&met, 4 * nb)); HOST_HIP(R.alloc(&status, (size_t)n * 4));
+  HOST_HIP(R.alloc(&d_send, WBC_NSTAT * 8)); HOST_HIP(R.alloc(&d_recv, (size_t)world * WBC_NSTAT * 8));
   // the shard's columns lo..hi-1 of every row: host leading dimension = whole batch, device leading dimension = shard
   HOST_HIP(hipMemcpy2D(q, nb, b.q.data() + lo, (size_t)ldh * 8, nb, 19, hipMemcpyHostToDevice));
   HOST_HIP(hipMemcpy2D(v, nb, b.v.data() + lo, (size_t)ldh * 8, nb, 18, hipMemcpyHostToDevice));
   HOST_HIP(hipMemcpy2D(tg, nb, b.tg.data() + lo, (size_t)ldh * 8, nb, 54, hipMemcpyHostToDevice));
   HOST_HIP(hipMemcpy(mask, b.mask.data() + lo, n, hipMemcpyHostToDevice));
   if (b.has_mu) {
-    HOST_HIP(hipMalloc(&mu, nb)); HOST_HIP(hipMalloc(&ms, nb));
+    HOST_HIP(R.alloc(&mu, nb)); HOST_HIP(R.alloc(&ms, nb));
     HOST_HIP(hipMemcpy(mu, b.mu.data() + lo, nb, hipMemcpyHostToDevice));
     HOST_HIP(hipMemcpy(ms, b.ms.data() + lo, nb, hipMemcpyHostToDevice));
   }
-  hipStream_t cs;   // the collective's stream
+  hipStream_t& cs = R.cs;   // the collective's stream
   HOST_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
   float ms_step = 0.f;
   // clock ramp (the GPU raises its clock over the first second of sustained load) and warm-up, as bench.py does
@@ -163,8 +201,10 @@ void rank_main(int rank, int world, const Options& o, const Batch& b, ncclComm_t
   for (int w = 0; w < o.warmup; w++) HOST_WBC(wbc_step(h, n, n, q, v, tg, mask, mu, ms, tau, met, status));
   HOST_WBC(wbc_sync(h));
   std::vector<double> gathered((size_t)world * WBC_NSTAT);
-  {   // warm the collective (RCCL channel set-up) outside the timed region
+  {   // warm the collective (RCCL channel set-up) outside the timed region; every rank has come through its set-up, or nobody enters
     HOST_WBC(wbc_stats_pack(h, res->packed));
+    bar->wait();
+    HOST_PEERS_OK();
     HOST_HIP(hipMemcpyAsync(d_send, res->packed, WBC_NSTAT * 8, hipMemcpyHostToDevice, cs));
     HOST_NCCL(ncclAllGather(d_send, d_recv, WBC_NSTAT, ncclDouble, comm, cs));
     HOST_HIP(hipStreamSynchronize(cs));
@@ -177,11 +217,13 @@ void rank_main(int rank, int world, const Options& o, const Batch& b, ncclComm_t
     HOST_WBC(wbc_time_steps(h, o.steps, n, n, q, v, tg, mask, mu, ms, tau, met, status, nullptr));   // K launches + two events, queued
     HOST_WBC(wbc_stats_pack(h, res->packed));                                                        // the one wait
     HOST_WBC(wbc_time_steps_result(h, &ms_step));
+    HOST_PEERS_OK();
     const auto tg0 = std::chrono::steady_clock::now();
     HOST_HIP(hipMemcpyAsync(d_send, res->packed, WBC_NSTAT * 8, hipMemcpyHostToDevice, cs));
     HOST_NCCL(ncclAllGather(d_send, d_recv, WBC_NSTAT, ncclDouble, comm, cs));                       // RCCL over xGMI: 176 bytes per rank
     HOST_HIP(hipMemcpyAsync(gathered.data(), d_recv, gathered.size() * 8, hipMemcpyDeviceToHost, cs));
     HOST_HIP(hipStreamSynchronize(cs));
+    HOST_PEERS_OK();   // (a collective released by a peer's ncclCommAbort has gathered nothing)
     const auto tg1 = std::chrono::steady_clock::now();
     HOST_WBC(wbc_stats_reduce(gathered.data(), world, &res->reduced));
     bar->wait();
@@ -199,11 +241,7 @@ void rank_main(int rank, int world, const Options& o, const Batch& b, ncclComm_t
   for (int32_t s : st_h) res->status_nonzero += (s != 0);
   int bt = 0;
   HOST_WBC(wbc_kernel_info(h, &res->num_vgpr, &res->scratch, &res->lds, &bt));
-  (void)hipStreamDestroy(cs);
-  void* bufs[] = {q, v, tg, mask, tau, met, status, mu, ms, d_send, d_recv};
-  for (void* p : bufs) if (p) (void)hipFree(p);
-  HOST_WBC(wbc_destroy(h));
-  res->ok = true;
+  res->ok = true;   // (stream, buffers and handle: ~RankResources)
 }
 
 void json_vec(std::string* s, const char* key, const std::vector<double>& x, const char* fmt) {
@@ -252,14 +290,19 @@ int main(int argc, char** argv) {
   }
   int rccl_version = 0;
   (void)ncclGetVersion(&rccl_version);
-  Barrier bar(world);
+  Team team(world, &comms);
   std::vector<RankResult> res(world);
   std::vector<std::thread> th;
-  for (int r = 0; r < world; r++) th.emplace_back(rank_main, r, world, std::cref(o), std::cref(b), comms[r], &bar, &res[r]);
+  for (int r = 0; r < world; r++) th.emplace_back(rank_main, r, world, std::cref(o), std::cref(b), comms[r], &team, &res[r]);
   for (auto& t : th) t.join();
-  for (int r = 0; r < world; r++) (void)ncclCommDestroy(comms[r]);
-  for (int r = 0; r < world; r++)
-    if (!res[r].ok) { fprintf(stderr, "wbc_host: rank %d failed: %s\n", r, res[r].err.c_str()); return 1; }
+  if (!team.failed.load())
+    for (int r = 0; r < world; r++) (void)ncclCommDestroy(comms[r]);     // (aborted communicators are already gone)
+  {
+    bool bad = false;
+    for (int r = 0; r < world; r++)
+      if (!res[r].ok) { fprintf(stderr, "wbc_host: rank %d failed: %s\n", r, res[r].err.c_str()); bad = true; }
+    if (bad) return 1;
+  }
   // MAX over ranks of the timed region, per repeat; the reported figures are the medians over the repeats
   std::vector<double> wall(o.repeat, 0.0), kms_max(o.repeat, 0.0), per_rank_kms(world), per_rank_ticks(world);
   for (int rep = 0; rep < o.repeat; rep++)
