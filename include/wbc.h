@@ -201,6 +201,16 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
                 double* time, double* targets, uint8_t* contact_mask, const double* mu,
                 const double* mass_scale, double* tau, double* metrics, int32_t* status, double* vdot);
 
+/* Warm-started active set inside wbc_rollout (default off).  The reference builds and solves a fresh QP every tick
+ * (inverse_dynamics_controller.py:200: a new MathematicalProgram).  A rollout keeps each robot on chip between its ticks, so the friction rows that
+ * were active when a robot's previous tick ended are free to remember; with on != 0 the active-set method adds those rows first (those of them that
+ * are violated: the method stays the same Goldfarb-Idnani iteration with another choice among the violated rows).  On closed loops that sit on their
+ * friction limits this rebuilds the set in as many steps as it has rows instead of 10 - 13 (profiles/r06/warm_start.md).  The QP is strictly convex,
+ * so the solution does not depend on that choice: outputs agree with the cold start to rounding (1e-9 relative over thousands of ticks), NOT bit for
+ * bit -- which is why it is an option: with the default (off) wbc_rollout stays bit-identical to the launch-per-stage loop.  A rollout call starts
+ * cold in either case (the memory does not outlive the launch); wbc_step is not affected. */
+int wbc_set_warm_start(wbc_handle h, int on);
+
 /* Kernel variant: 0 = auto (default) or 3 = 16 lanes (one DPP row) per robot -- the one product kernel family for
  * every law, batch size and option.  (1 = lane-per-robot and 2 = quad-per-robot were round-1 mappings that lost at
  * every batch size and are retired: the call rejects them.) */

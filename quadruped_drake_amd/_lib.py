@@ -15,7 +15,7 @@ DEVICE_PTRS, HOST_PTRS = 0, 1
 
 # every symbol include/wbc.h (the controller interface) and include/wbc_extras.h (frozen out-of-scope exports) declare
 SYMBOLS = ["wbc_last_error", "wbc_version", "wbc_params_default", "wbc_create", "wbc_destroy", "wbc_set_stream",
-           "wbc_step", "wbc_sync", "wbc_time_steps", "wbc_time_steps_result", "wbc_time_steps_each", "wbc_stats_get", "wbc_stats_reset", "wbc_stats_pack", "wbc_stats_reduce", "wbc_set_variant", "wbc_set_vdot_output", "wbc_integrate", "wbc_rollout",
+           "wbc_step", "wbc_sync", "wbc_time_steps", "wbc_time_steps_result", "wbc_time_steps_each", "wbc_stats_get", "wbc_stats_reset", "wbc_stats_pack", "wbc_stats_reduce", "wbc_set_variant", "wbc_set_warm_start", "wbc_set_vdot_output", "wbc_integrate", "wbc_rollout",
            "wbc_kernel_info", "wbc_rollout_kernel_info", "wbc_variant_for", "wbc_trunk_state_decode", "wbc_trunk_state_to_targets", "wbc_traj_create",
            "wbc_traj_destroy", "wbc_traj_lookup", "wbc_robot_state_decode", "wbc_robot_state_encode",
            "wbc_robot_states_unpack", "wbc_robot_controls_pack", "wbc_pd_step"]
@@ -91,6 +91,7 @@ def lib():
             l.wbc_stats_pack.argtypes = [C.c_void_p, c_double_p]
             l.wbc_stats_reduce.argtypes = [c_double_p, C.c_int, C.POINTER(WbcStats)]
         l.wbc_set_variant.argtypes = [C.c_void_p, C.c_int]
+        l.wbc_set_warm_start.argtypes = [C.c_void_p, C.c_int]
         l.wbc_variant_for.argtypes = [C.c_void_p, C.c_int]
         l.wbc_set_vdot_output.argtypes = [C.c_void_p, C.c_void_p]
         l.wbc_integrate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]

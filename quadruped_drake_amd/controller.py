@@ -285,6 +285,12 @@ class BatchedController:
         self._keep = (tg, mk, tau, met, st, vd, mu, mass_scale)
         return tau, met, st, tg, mk
 
+    def set_warm_start(self, on=True):
+        """rollout(): start every tick's active set from the rows that were active when the robot's previous tick ended (wbc_set_warm_start).  The
+        reference solves every tick from scratch (inverse_dynamics_controller.py:200); the result is the same QP solution to rounding, reached in fewer
+        active-set trips on closed loops that sit on their friction limits.  Off by default: a cold rollout equals the launch-per-stage loop bit for bit."""
+        _lib.check(self._L.wbc_set_warm_start(self._h, 1 if on else 0))
+
     def set_variant(self, variant):
         """"auto" (0) or "hex" (3): the 16-lanes-per-robot kernel is the one product kernel family."""
         v = {"auto": 0, "hex": 3}.get(variant, variant)

@@ -181,11 +181,20 @@ WBC_HD int hex_pick_index(double k) {
 // joint in a second constraint slot (id 32 + lane): unit normal Tn of the torque-map row, normalised torque
 // yt = Tn.z + t0n tracked like s_h, bound bt = tau_max / |T_row| (< 0: slot not eligible).  Only one side of a
 // pair can be violated or active at a time; the side is a sign (sig) applied to the slot's image.
-template <class Q, bool PC, int NV = NZ, bool TB = false, bool GAIN = false, bool HYB = false>
+// WARM (the persistent rollout kernels; wbc_set_warm_start): `*seed` says, per lane, whether this lane's friction row was active when the robot's PREVIOUS
+// tick ended.  Goldfarb-Idnani may add any violated row; a seeded row that is violated is preferred to every other candidate (its pick key is pushed to
+// -HEX_SEED: the exact value of a picked row is fetched from its lane anyway), so a closed loop whose active set moves little from tick to tick rebuilds it
+// in as many full-step adds as it has rows -- the fast path's compile-time trips -- instead of finding it again through the cold start's detours and drops
+// (profiles/r06/warm_start.md: 10 - 13 trips per tick -> the size of the set on saturated closed loops).  Everything else is the same algorithm: same
+// tolerance, same steps, same exit; the QP is strictly convex, so the solution does not depend on the order of the adds (outputs agree with the cold start
+// to rounding, not bit for bit).  On return `*seed` = this lane's row is active NOW.  With WARM = false (the tick kernels) none of this is compiled.
+constexpr double HEX_SEED = 1e295;
+template <class Q, bool PC, int NV = NZ, bool TB = false, bool GAIN = false, bool HYB = false, bool WARM = false>
 WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, double inv_s, int* iters_out,
                   double vrow_own = 0.0, double vc = 0.0, double pc_inv = 0.0, const double* Tn = nullptr,
-                  double t0n = 0.0, double bt = -1.0, bool deep = true) {
+                  double t0n = 0.0, double bt = -1.0, bool deep = true, bool* seed = nullptr) {
   const int sb = h & 3;
+  const double seed_bias = (WARM && *seed) ? HEX_SEED : 0.0;   // subtracted from the pick key of this lane's row while it is a violated candidate
   const bool pc = PC && pc_inv > 0.0;
   WBC_GI_STAT(if (g_gi_dump) { double* o = g_gi_dump + h * 16; for (int k = 0; k < NV && k < 13; k++) o[k] = Jr[k]; o[13] = z; o[14] = mu_n; o[15] = ct ? inv_s : 0.0; });
   const double sg = (sb & 1) ? inv_s : -inv_s;   // own row: n_h = sg * e_(leg, sb>>1) + mu_n * e_(leg, 2)
@@ -268,6 +277,8 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   const double INF = __builtin_huge_val();
   // feasibility tolerance from the scale of the unconstrained minimiser (the iterates stay on that scale)
   const double tol = 1e-13 * (1.0 + qo.max16(fabs(z)));
+  // the most-violated rule's key of this lane's row: its value -- pushed down by the seed bias while the row is violated (a seeded row that is satisfied is no candidate)
+  auto warm_key = [&](double v) -> double { if constexpr (WARM) return (v < -tol) ? v - seed_bias : v; else return v; };
   // ---- Fast path (plain friction rows only): the first trips of a tick are almost always "add the picked row with a
   // full step" on every robot of the wavefront, so the list length q is wave-uniform and equals the trip number.  With q
   // a compile-time constant the position masks and all work on the fixed positions k < q disappear.  The moment any
@@ -309,13 +320,13 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
             static_for<NV - qc>([&](auto KK) { constexpr int k = qc + KK; dd2 = fmad(Dh[k], Dh[k], dd2); });
             if constexpr (HYB) {
               const double gk = (dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290;
-              if (!use_gain) key = pick_pack(sh_, h);
-              else if (sh_ < -tol) key = pick_pack(gk, h);
+              if (!use_gain) key = pick_pack(warm_key(sh_), h);
+              else if (sh_ < -tol) key = pick_pack(gk - seed_bias, h);
             } else {
-              if (sh_ < -tol) key = pick_pack((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
+              if (sh_ < -tol) key = pick_pack(((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290) - seed_bias, h);
             }
           } else {
-            key = pick_pack(sh_, h);
+            key = pick_pack(warm_key(sh_), h);
           }
         }
         key = qo.min16(key);
@@ -441,15 +452,15 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
             if constexpr (HYB) {
               const double gk = (dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290;
               if (ct && !act_h && !(APEX && nleg == 3)) {
-                if (!use_gain) key = pick_pack(sh_, h);
-                else if (sh_ < -tol) key = pick_pack(gk, h);
+                if (!use_gain) key = pick_pack(warm_key(sh_), h);
+                else if (sh_ < -tol) key = pick_pack(gk - seed_bias, h);
               }
             } else {
               if (ct && !act_h && !(APEX && nleg == 3) && sh_ < -tol)
-                key = pick_pack((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290, h);
+                key = pick_pack(((dd2 > 1e-22 * dnh) ? -(sh_ * sh_) * fast_rcp(dd2) : -1e290) - seed_bias, h);
             }
           } else {
-            if (ct && !act_h && !(APEX && nleg == 3)) key = pick_pack(sh_, h);
+            if (ct && !act_h && !(APEX && nleg == 3)) key = pick_pack(warm_key(sh_), h);
           }
           if (TB) {
             const double st_ = bt - fabs(yt);
@@ -759,6 +770,7 @@ WBC_HD int hex_gi(Q& qo, int h, bool ct, double* Jr, double& z, double mu_n, dou
   z = (h == 3) ? 0.0 : z;   // lane (0, 3): y . d garbage (see the entry check); no 16-lane reduction downstream may pick it up
   *iters_out = iters;
   if (!done && status == ST_OK) status = ST_ITER;
+  if constexpr (WARM) *seed = act_h;
   return status;
 }
 
@@ -835,9 +847,9 @@ WBC_HD double pick3(int sb, double a, double b, double c) { return (sb == 0) ? a
 
 // The tick.  Every lane of the row calls this with its own Q (lane id h = 4*leg + sub).
 // out_tau(row, x): lane (leg, j<3) writes the torque of joint 3*leg+j;  out_met: see the kernel.
-template <class Q, int KIND, bool TB, class Park, class In, class OutTau, class OutMet>
+template <class Q, int KIND, bool TB, bool WARM = false, class Park, class In, class OutTau, class OutMet>
 WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned mask, double mu, double mass_scale,
-                    Park& pk, OutTau out_tau, OutMet out_met, int* iters_out) {
+                    Park& pk, OutTau out_tau, OutMet out_met, int* iters_out, bool* seed = nullptr) {
   const int h = qo.lane();
   const int l = h >> 2, sb = h & 3;
   const bool ct = (mask >> l) & 1u;
@@ -1519,13 +1531,13 @@ WBC_HD int hex_tick(const ModelC& m, const ParamsX& P, Q& qo, In in, unsigned ma
     (void)s;
     int st;
     if (KIND == KIND_PC) {
-      st = hex_gi<Q, true, NV, TB, !TB, true>(qo, h, ct, Jr, z, mu * rs, rs, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt, deep);
+      st = hex_gi<Q, true, NV, TB, !TB, true, WARM>(qo, h, ct, Jr, z, mu * rs, rs, &iters, pc_vr, pc_c, pc_inv, Tn, t0n, bt, deep, seed);
     } else if (KIND == KIND_CLF) {
       // the CLF row  g . [z; delta] - ub <= 0  is the dense row of the active set (index 16), like PC's Vdot row
-      st = hex_gi<Q, true, NV, TB, !TB, true>(qo, h, ct, Jr, z, mu * rs, rs, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt, deep);
+      st = hex_gi<Q, true, NV, TB, !TB, true, WARM>(qo, h, ct, Jr, z, mu * rs, rs, &iters, clf_g, -clf_ub, clf_inv, Tn, t0n, bt, deep, seed);
     } else {
       // pick rule of the friction-only laws, fixed at compile time: MPTC greatest dual gain, ID most violated row (gain pivoting for ID: 12.3 vs 11.4 trips)
-      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC) && !TB>(qo, h, ct, Jr, z, mu * rs, rs, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt, deep);
+      st = hex_gi<Q, false, NV, TB, (KIND == KIND_MPTC) && !TB, false, WARM>(qo, h, ct, Jr, z, mu * rs, rs, &iters, 0.0, 0.0, 0.0, Tn, t0n, bt, deep, seed);
     }
     if (st != ST_OK) status = st;
     if (status == ST_OK && illc) status = ST_ILLCOND;

@@ -454,7 +454,7 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* _
                        double dt, wbc::TrajDev T, double* __restrict__ q, double* __restrict__ v, double* __restrict__ time,
                        double* __restrict__ tg, uint8_t* __restrict__ mask, const double* __restrict__ mu,
                        const double* __restrict__ ms, double* __restrict__ tau, double* __restrict__ met,
-                       int32_t* __restrict__ status, StatsDev* __restrict__ stats, double* __restrict__ vdot) {
+                       int32_t* __restrict__ status, StatsDev* __restrict__ stats, double* __restrict__ vdot, int warm) {
   constexpr int PER_LANE = (NIN * HROBOTS + HEX_BLOCK - 1) / HEX_BLOCK;
   constexpr int MPER = (MODEL_PAD_WORDS + HEX_BLOCK - 1) / HEX_BLOCK;
   constexpr int NST = 37;   // state rows q (19) + v (18)
@@ -491,6 +491,10 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* _
   __syncthreads();
   auto in = [&](int r) -> double { return inbuf[r * HROBOTS + slot]; };
   ParkLds park(parkbuf + slot * wbc::PK_N, lanebuf + threadIdx.x);
+  // Warm start (wbc_set_warm_start; wbc_hex.hpp: hex_gi<..., WARM>): was this lane's friction row active when the robot's previous tick ended?  The robot
+  // stays on this wavefront for the whole rollout, so last tick's active set is one bit per lane that never leaves the chip.  `warm` = 0 (the default):
+  // the bit is never set and every pick is the cold start's -- the rollout then equals the launch-per-stage loop bit for bit.
+  bool seed = false;
   for (int step = 0; step < steps; step++) {
     // The model table and the parameters are loop-invariant, and the compiler would hoist ~130 doubles of them out
     // of the step loop into registers (the kernel then spills): an opaque zero offset per iteration keeps those
@@ -531,7 +535,9 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* _
       if (k == 1) errv = x;
     };
     int iters = 0;
-    const int st = wbc::hex_tick<HexDev, KIND, TB>(m, P, qo, in, mk, mui, msi, park, ot, om, &iters);
+    bool sd = seed;
+    const int st = wbc::hex_tick<HexDev, KIND, TB, true>(m, P, qo, in, mk, mui, msi, park, ot, om, &iters, &sd);
+    seed = (warm != 0) && (st == wbc::ST_OK) && sd;     // (a tick that was not solved leaves nothing worth starting from)
     if (lead) { outbuf[slot * 18 + 16] = (double)st; outbuf[slot * 18 + 17] = (double)mk; }
     if (stats) {
       const double ts = qo.sum16(tsum), tm = qo.max16(tmax);
@@ -654,6 +660,7 @@ struct wbc_handle_s {
   uint32_t flags;
   hipStream_t stream;
   bool own_stream;
+  bool warm_start;   // wbc_set_warm_start: wbc_rollout seeds every tick's active set with the previous tick's
   wbc::ModelC* d_model;
   wbc::ParamsX* d_params;
   StatsDev* d_stats;
@@ -1069,7 +1076,7 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
     StatsDev* d_stats = h->d_stats;
     dim3 grid((n + HROBOTS - 1) / HROBOTS);
 #define WBC_RO_ARGS grid, dim3(HEX_BLOCK), 0, h->stream, h->d_model, h->d_params, n, ld, steps, dt, T, q, v, time, targets, \
-                    contact_mask, mu, mass_scale, tau, metrics, status, d_stats, vdot
+                    contact_mask, mu, mass_scale, tau, metrics, status, d_stats, vdot, (h->warm_start ? 1 : 0)
 #define WBC_RO_KIND(TBV)                                                                                   \
     switch (h->kind) {                                                                                     \
       case WBC_KIND_ID: hipLaunchKernelGGL((wbc_hex_rollout_kernel<wbc::KIND_ID, TBV>), WBC_RO_ARGS); break;     \
@@ -1089,6 +1096,12 @@ int wbc_rollout(wbc_handle h, wbc_traj traj, int steps, double dt, int n, int ld
     return 0;
   }
 #endif
+}
+
+int wbc_set_warm_start(wbc_handle h, int on) {
+  if (!h) return misuse("wbc_set_warm_start: null handle");
+  h->warm_start = on != 0;
+  return 0;
 }
 
 int wbc_set_variant(wbc_handle h, int variant) {

@@ -312,3 +312,92 @@ def test_no_product_kernel_spills(tau_max):
         c.close()
         assert tick["scratch_bytes_per_lane"] == 0 and ro["scratch_bytes_per_lane"] == 0, (cls.__name__, tick, ro)
         assert 0 < tick["num_regs"] <= 512 and 0 < ro["num_regs"] <= 512
+
+
+def _sway_trajectory(dt, duration=2.0, amp=0.05, hz=2.0):
+    """Body target swaying sideways harder than friction allows at the peaks (amp (2 pi hz)^2 = 7.9 m/s^2 against mu g = 6.9): a closed loop
+    that sits on its friction limits for part of every period (tools/lab/r06/warm_probe.py)."""
+    ts = np.arange(int(round(duration / dt)) + 1) * dt
+    tg = workloads.standing_targets("mini_cheetah", ts.size)
+    w = 2 * np.pi * hz
+    tg[1] += amp * np.sin(w * ts); tg[4] = amp * w * np.cos(w * ts); tg[7] = -amp * w * w * np.sin(w * ts)
+    return ts, np.ascontiguousarray(tg.T), np.full(ts.size, 0b1111, np.uint8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,dt,steps,amp", [("mptc", 1e-3, 200, 0.05), ("id", 5e-3, 100, 0.05), ("pc", 1e-3, 10, 0.03), ("clf", 5e-3, 10, 0.036)])   # (all four rollout kernels)
+def test_warm_started_rollout_is_the_cold_rollout_in_fewer_trips(kind, dt, steps, amp):
+    """wbc_set_warm_start (include/wbc.h; csrc/wbc_hex.hpp: hex_gi<..., WARM>): every tick of a rollout starts its active set from the friction rows that were
+    active when the robot's previous tick ended, where the reference -- and the default -- solve every tick from scratch
+    (inverse_dynamics_controller.py:200).  Same strictly convex QP, another order of the adds: on a closed loop that sits on its friction limits the
+    torques, accelerations and the state after `steps` ticks agree with the cold rollout to the accuracy either has on saturated ticks (the bar of
+    tests/test_gpu_parity.py for 4-contact stands on their friction limits, 2e-6: there the solution is carried at 1 / eps = 1e4 in the internal-force
+    directions; measured 2.4e-7 after 200 closed-loop ticks), in markedly fewer active-set trips.  (The PC / CLF laws' hard rows make harder sways
+    infeasible after some tens of ticks -- tools/lab/r06/pc_clf_sway_probe.py: a closed loop on its way there amplifies the last bits of every
+    tick -- so they sway a little less and are compared over ten ticks: what is tested for them is the seeded active set, tick by tick.)"""
+    import torch
+    from quadruped_drake_amd import IDController, MPTCController, PCController, CLFController
+    from quadruped_drake_amd.trajectory import TrunkTrajectory
+    cls = {"mptc": MPTCController, "id": IDController, "pc": PCController, "clf": CLFController}[kind]
+    n = 512
+    ts, tg, masks = _sway_trajectory(dt, amp=amp)
+    traj = TrunkTrajectory(ts, tg, masks, wait_time=0.0, device=0)
+    q0, v0 = workloads.nominal_state("mini_cheetah", n)
+    rng = np.random.default_rng(5)
+    q0[7:] += rng.uniform(-0.05, 0.05, (12, n)); v0[0:6] = rng.normal(0, 0.05, (6, n))
+    t0 = rng.uniform(0.0, 0.5, n)
+    dev = "cuda:0"
+    res = {}
+    for warm in (False, True):
+        c = cls(max_batch=n, device=0)
+        c.set_warm_start(warm)
+        q = torch.tensor(q0, device=dev); v = torch.tensor(v0, device=dev); t = torch.tensor(t0, device=dev)
+        tau, met, st, tgo, mk = c.rollout(traj, steps, dt, q, v, t)
+        c.sync()
+        res[warm] = dict(q=q.cpu().numpy(), v=v.cpu().numpy(), tau=tau.cpu().numpy(), st=st.cpu().numpy(), vd=c._keep[5].cpu().numpy(), stats=c.stats())
+        c.close()
+    traj.close()
+    cold, warm = res[False], res[True]
+    it_c, it_w = cold["stats"]["iters_sum"] / cold["stats"]["ticks"], warm["stats"]["iters_sum"] / warm["stats"]["ticks"]
+    assert it_c > 2.0, it_c                                   # the loop really sits on its friction rows
+    assert cold["stats"]["status_nonzero"] == 0 and warm["stats"]["status_nonzero"] == 0
+    assert it_w < (0.8 if kind in ("mptc", "id") else 0.95) * it_c, (it_c, it_w)      # measured: 8.0 -> 5.0 (MPTC), 9.1 -> 6.8 (ID)
+    ok = np.ones(n, bool)
+    scale = lambda a: np.maximum(np.abs(a).max(0), 1e-3)
+    loose = 1.0 if kind in ("mptc", "id") else 5.0          # (PC / CLF stands: 1e-5, tests/test_gpu_parity.py)
+    for k, bar in (("tau", 2e-6 * loose), ("vd", 2e-6 * loose), ("q", 1e-8), ("v", 1e-6 * loose)):
+        err = (np.abs(warm[k] - cold[k]).max(0) / scale(cold[k]))[ok].max()
+        assert err < bar, (k, err)
+    print("%s: %.2f -> %.2f trips per tick, %d of %d robots compared, status != 0 on %d / %d ticks" % (kind, it_c, it_w, ok.sum(), n, cold["stats"]["status_nonzero"], warm["stats"]["status_nonzero"]))
+
+
+@pytest.mark.gpu
+def test_warm_start_is_off_by_default_and_a_trot_needs_no_tolerance():
+    """Default handles never seed (the persistent rollout stays bit-identical to the launch-per-stage loop: test_persistent_rollout_equals_launch_per_stage).
+    With the option on, a trot rollout -- one or two active rows per tick -- still agrees with the cold one far below any bar a test here uses."""
+    import torch
+    from quadruped_drake_amd import MPTCController
+    from quadruped_drake_amd.trajectory import TrunkTrajectory
+    n, steps, dt = 203, 120, 1e-3
+    ts, tg, masks, st_t = _trot_trajectory()
+    traj = TrunkTrajectory(ts, tg, masks, wait_time=0.03, device=0, standing_targets=st_t, standing_mask=0b1111)
+    q0, v0 = workloads.nominal_state("mini_cheetah", n)
+    rng = np.random.default_rng(11)
+    q0[7:] += rng.uniform(-0.05, 0.05, (12, n)); v0[0:6] = rng.normal(0, 0.05, (6, n))
+    t0 = rng.uniform(0.0, 0.25, n)
+    out = []
+    for mode in ("default", "off", "on"):
+        c = MPTCController(max_batch=n, device=0)
+        if mode != "default":
+            c.set_warm_start(mode == "on")
+        q = torch.tensor(q0, device="cuda:0"); v = torch.tensor(v0, device="cuda:0"); t = torch.tensor(t0, device="cuda:0")
+        tau, met, st, _, _ = c.rollout(traj, steps, dt, q, v, t); c.sync()
+        out.append((q.cpu().numpy(), v.cpu().numpy(), tau.cpu().numpy(), c.stats()["iters_sum"]))
+        c.close()
+    traj.close()
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(a, b)
+    assert out[0][3] == out[1][3]
+    for a, b in zip(out[1][:3], out[2][:3]):
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(a).max())
+    assert out[2][3] <= 1.05 * out[1][3] + 2      # (a trot has next to nothing to seed: 65 trips in 24 360 ticks, cold)
