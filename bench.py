@@ -204,6 +204,7 @@ def cpu_baseline(batch, seconds):
     orc.bench_batch("id", mid, pid, q0, v0, tg0, mk0, nthreads=1, reps=1200)
     c1 = time.perf_counter() - t0
     return {"value": rate, "unit": "ticks/s", "cores": min(use, cores), "threads": use, "kind": "port",
+            "reduced": cpu_baseline_reduced(batch, use, max(2.0, seconds / 4.0)),
             "single_core_ticks_per_s": rate1, "thread_scaling_ticks_per_s": curve, "host": lim,
             "build": "gcc -O3 -march=x86-64-v3 -fopenmp -ffp-contract=off (oracle/Makefile)",
             "config1": {"workload": "BASELINE configs[0] restated: 1 Mini Cheetah, ID law, q0 of simulate.py:171-176, "
@@ -211,6 +212,49 @@ def cpu_baseline(batch, seconds):
                         "ticks_per_s": 1200.0 / c1, "realtime_factor_at_200Hz": (1200.0 / c1) / 200.0},
             "sample": "the same %d-instance batch x %d passes on %d threads (one OpenMP region, dynamic schedule); C oracle = "
                       "dense restatement of the Drake+OSQP tick, NOT Drake+OSQP" % (n, reps, use)}
+
+
+def cpu_baseline_reduced(batch, threads, seconds):
+    """CONTEXT beside the literal port: the REDUCED algorithm the kernels run (12-variable QP, QR + Goldfarb-Idnani; the scalar one-robot host
+    instantiation of tools/wbc_scalar_tick.hpp through tools/libhost_tick.so), same batch, same thread count.  4 - 5 x fewer flops than the dense
+    restatement of the Drake + OSQP tick: the honest CPU figure for the algorithm the GPU runs -- never the thing measured or shipped, never the target."""
+    import ctypes as C
+    import numpy as np
+    so = os.path.join(ROOT, "tools", "libhost_tick.so")
+    try:
+        L = C.CDLL(so)
+        fn = L.host_tick_bench
+    except (OSError, AttributeError) as e:
+        return {"value": None, "why": "tools/libhost_tick.so not built (%s)" % e}
+    from oracle import oracle_py as orc
+    n = batch["n"]
+    dp = C.POINTER(C.c_double)
+    flat = np.ascontiguousarray(orc.load_model_json(batch["model"])["flat"], dtype=np.float64)
+    q, v, tg = (np.ascontiguousarray(batch[k], dtype=np.float64) for k in ("q", "v", "targets"))
+    mask = np.ascontiguousarray(batch["mask"], dtype=np.uint8)
+    mu = None if batch["mu"] is None else np.ascontiguousarray(batch["mu"], dtype=np.float64)
+    ms = None if batch["mass_scale"] is None else np.ascontiguousarray(batch["mass_scale"], dtype=np.float64)
+    tau = np.zeros((12, n)); st = np.zeros(n, np.int32)
+    kind = {"id": 0, "mptc": 1, "pc": 2, "clf": 3}[batch["kind"]]
+    P = lambda a: None if a is None else a.ctypes.data_as(dp)
+
+    def timed(th, reps):
+        t0 = time.perf_counter()
+        rc = fn(kind, P(flat), n, n, P(q), P(v), P(tg), mask.ctypes.data_as(C.POINTER(C.c_ubyte)), P(mu), P(ms), P(tau), st.ctypes.data_as(C.POINTER(C.c_int)),
+                int(th), int(reps))
+        if rc != 0:
+            raise RuntimeError("host_tick_bench rc %d" % rc)
+        return n * reps / (time.perf_counter() - t0)
+
+    r1 = timed(1, 1)
+    rate1 = timed(1, max(1, int(round(r1 * 1.0 / n))))
+    reps = max(1, int(round(rate1 * threads * seconds / n)))
+    rate = timed(threads, reps)
+    return {"value": rate, "unit": "ticks/s", "threads": int(threads), "single_core_ticks_per_s": rate1, "kind": "port-reduced",
+            "status_nonzero": int((st != 0).sum()),
+            "build": "g++ -O2 -ffp-contract=off (tools/host_tick.cpp, built by build())",
+            "sample": "the same %d-instance batch x %d passes on %d std::threads (chunks of 8 from an atomic counter); the kernels' reduced 12-variable "
+                      "algorithm as a scalar one-robot host instantiation -- context for the GPU figure, not a baseline to beat" % (n, reps, threads)}
 
 
 def closed_loop(shard, device, steps=300):
@@ -521,14 +565,32 @@ def run_rank(a):
         achieved = flops * n / sec / 1e12
         # HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
         # (separate runs; committed under profiles/): null when no measurement matches this build
-        traffic = None
+        traffic, traffic_source = None, "none: profiles/hbm_traffic.json holds no PMC pass of this kernel build"
         try:
             with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
                 tr = json.load(f)
             ent = tr.get("%s_cfg%d_n%d_%s" % (shard["kind"], cfg, n, used))
             if ent and ent.get("kernel_src_sha16") == kernel_src_sha16():     # counters of another kernel build are not mixed in
                 traffic = ent["bytes_per_launch"]
+                # REPLAYED, not measured in this run: the builder's committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, separate runs of this
+                # command on another box), admitted only for the very kernel sources this process runs
+                traffic_source = "replayed: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, %s; kernel sources sha16 %s)" % (
+                    ent.get("source", "committed by the builder"), ent["kernel_src_sha16"])
         except (OSError, ValueError):
+            pass
+        # the committed profiler summary of this kernel (rocprofv3 --kernel-trace --stats, profiles/<round>/kernel_stats.csv) was collected on ANOTHER box of
+        # the pool: its average launch time gives `frac_profile_box`, stated beside `frac` (this run, HIP events) so that the two cannot be confused
+        frac_profile_box, profile_box_us = None, None
+        try:
+            import csv
+            with open(os.path.join(ROOT, "profiles", PMC_ROUND, "kernel_stats.csv")) as f:
+                for row in csv.reader(f):
+                    if row and "wbc_hex_kernel<%d, false>" % {"id": 0, "mptc": 1, "pc": 2, "clf": 3}[shard["kind"]] in row[0]:
+                        profile_box_us = float(row[3]) / 1e3                 # AverageNs
+                        break
+            if profile_box_us and cfg == 3 and n == 4096:
+                frac_profile_box = flops * n / (profile_box_us * 1e-6) / 1e12 / PEAK_FP64_VALU_TFLOPS
+        except (OSError, ValueError, IndexError):
             pass
         # what the issue slots did (same separate-pass PMC file, committed): executed FP64 flops include the arithmetic the
         # 16-lane mapping replicates on sub-lanes, so they say how busy the ALU was, not how much of it was useful
@@ -572,7 +634,10 @@ def run_rank(a):
                 "instances_per_gpu": n, "seed": shard["seed"],
                 "domain_randomised": mu is not None, "parallelism": "batch-shard x%d" % world},
             "roofline": {"bound": "fp64-valu", "achieved": achieved, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_FP64_VALU_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac_profile_box": frac_profile_box, "profile_box_kernel_us": profile_box_us,
+                         "frac_note": "frac = THIS run (HIP events around the K timed launches on this box); frac_profile_box = the committed rocprofv3 summary "
+                                      "profiles/%s/kernel_stats.csv, another box of the pool (boxes differ by up to 5 %%)" % PMC_ROUND,
                          "kernel": "wbc_hex_kernel<%d, false>" % {"id": 0, "mptc": 1, "pc": 2, "clf": 3}[shard["kind"]],   # the name rocprofv3 prints
                          "kernel_law": shard["kind"].upper(),
                          "kernel_ms": ms_per_launch, "flops_per_tick": flops, "issued": issued,

@@ -332,13 +332,14 @@ class BatchedController:
         self.last_status = st
         if st == 3 and not self.strict:
             import warnings
-            # EVERY flagged tick is visible: Python's default filter shows a warning once per call site (keyed on text + line number
-            # in the module's __warningregistry__), which would silence a control loop after its first ill-conditioned tick -- so
-            # the text carries the running count and the call goes through warn_explicit with the count as its line number
+            # n_illcond counts EVERY flagged tick; the warning is throttled to the 1st, 2nd, 4th, 8th ... of them (a 1 kHz loop in an
+            # ill-conditioned pose would otherwise print a thousand lines a second).  The text carries the count, so Python's default
+            # "once per location and text" filter does not swallow the later ones; the location is the caller's (stacklevel 2).
             self.n_illcond += 1
-            warnings.warn_explicit("whole-body QP tick flagged with status 3 (%s) [flagged tick #%d of this controller; "
-                                   "last_status / n_illcond]" % (STATUS_TEXT[3], self.n_illcond), IllConditionedWarning,
-                                   filename=__file__, lineno=self.n_illcond, module=__name__, registry={})
+            if self.n_illcond & (self.n_illcond - 1) == 0:
+                warnings.warn("whole-body QP tick flagged with status 3 (%s) [flagged tick #%d of this controller -- every flagged tick is "
+                              "counted in n_illcond and visible in last_status; this message appears at #1, #2, #4, #8, ...]"
+                              % (STATUS_TEXT[3], self.n_illcond), IllConditionedWarning, stacklevel=2)
         elif st != 0:
             raise SolverError("whole-body QP failed with status %d (%s)" % (st, STATUS_TEXT.get(st, "unknown")), st, tau)
         self.V, self.err, self.res, self.Vdot = (float(x) for x in met)

@@ -361,13 +361,16 @@ def test_ill_conditioned_ticks_are_reported_not_hidden():
     with pytest.warns(IllConditionedWarning):
         u = c.ControlLaw(q[:, 0], b["v"][:, 0], d)
     assert c.last_status == 3 and np.isfinite(u).all() and np.abs(u).max() > 0
-    # ... on EVERY flagged tick of a control loop, not once per call site (Python's default filter), and counts them
+    # ... counts EVERY flagged tick of a control loop and warns at the 1st, 2nd, 4th, 8th ... of them (not once per call site -- Python's default
+    # filter -- and not a thousand times a second either); the warning points at the caller's line, not into the library
     import warnings
     with warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("default")
-        for _ in range(3):
+        for _ in range(8):
             c.ControlLaw(q[:, 0], b["v"][:, 0], d)
-    assert len([w for w in rec if issubclass(w.category, IllConditionedWarning)]) == 3 and c.n_illcond == 4
+    ill = [w for w in rec if issubclass(w.category, IllConditionedWarning)]
+    assert c.n_illcond == 9 and len(ill) == 3 and all(w.filename == __file__ for w in ill)          # flagged ticks #2, #4, #8
+    assert "#8" in str(ill[-1].message)
     c.close()
     # ... unless asked to be strict
     c = MPTCController(max_batch=1, device=0, strict=True)

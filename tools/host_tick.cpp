@@ -6,6 +6,9 @@
 // The shipped library (libwbc_hip.so) never calls this; it has no CPU path.
 #include <math.h>
 #include <stdlib.h>
+#include <atomic>
+#include <thread>
+#include <vector>
 #include <stdint.h>
 #include <string.h>
 #include "../quadruped_drake_amd/csrc/wbc_model.hpp"
@@ -81,6 +84,40 @@ int host_tick_batch(int kind, const double* flat215, const double* params12, con
 }
 
 void host_set_vdot_sink(double* vdot) { g_vdot = vdot; }
+
+// Timing driver for bench.py's cpu_baseline.reduced: `reps` passes over the n instances of the REDUCED algorithm the kernels run (12-variable QP, QR +
+// Goldfarb-Idnani: the scalar one-robot instantiation of tools/wbc_scalar_tick.hpp), instances dealt to `nthreads` std::threads in contiguous chunks.
+// Outputs of the last pass are kept.  Context beside the literal dense port of oracle/, never the thing measured or shipped.
+int host_tick_bench(int kind, const double* flat215, int n, int stride, const double* q, const double* v, const double* tg,
+                    const unsigned char* mask, const double* mu, const double* mass_scale, double* tau, int* status, int nthreads, int reps) {
+  wbc::ModelC m;
+  if (wbc::model_from_flat(flat215, &m) || g_vdot) return -1;
+  wbc::model_set_perms(&m, nullptr, nullptr);
+  wbc::ParamsC P;
+  wbc::params_default(kind, &P);
+  if (nthreads < 1) nthreads = 1;
+  std::vector<double> met((size_t)4 * stride);
+  // chunks of 8 instances (one cache line of every output row) handed out by an atomic counter: the oracle's `schedule(dynamic, 8)`
+  std::atomic<long long> next{0};
+  const long long chunks_per_pass = (n + 7) / 8, total = chunks_per_pass * reps;
+  auto work = [&](int) {
+    for (;;) {
+      const long long c = next.fetch_add(1);
+      if (c >= total) break;
+      const int lo = (int)(c % chunks_per_pass) * 8, hi = lo + 8 < n ? lo + 8 : n;
+      for (int i = lo; i < hi; i++) {
+        int it = 0;
+        const int st = run_one<double>(kind, m, P, i, stride, q, v, tg, mask[i], mu ? mu[i] : P.mu, mass_scale ? mass_scale[i] : 1.0, tau, met.data(), &it);
+        if (status) status[i] = st;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  return 0;
+}
 
 // Mean operation counts per tick over the batch: out[6] = add, mul, div, sqrt, trig, cmp.
 int host_tick_count(int kind, const double* flat215, const double* params12, int n, int stride,
