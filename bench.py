@@ -39,7 +39,7 @@ FLOPS_PER_TICK = {("mptc", 3): 37629.0, ("mptc", 5): 37703.0, ("id", 2): 35667.0
 BYTES_PER_TICK = {False: 864.0, True: 880.0}     # SURVEY.md section 8(d); True = with mu and mass scale
 PEAK_FP64_VALU_TFLOPS = 78.6                      # MI355X vector FP64 (spec); FP64 MFMA peak is the same figure
 PEAK_HBM_GBS = 8000.0
-PMC_ROUND = "r05"                                  # profiles/<round>/hex_pmc.json: the committed counter pass roofline.issued restates
+PMC_ROUND = "r06"                                  # profiles/<round>/hex_pmc.json: the committed counter pass roofline.issued restates
 
 
 # what the identity of a kernel build covers: an explicit list (a stray backup file under csrc/ does not change it)

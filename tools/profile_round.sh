@@ -4,7 +4,7 @@
 #   PMC passes (separate runs; --pmc is never combined with sys/hip traces) for the headline MPTC kernel, for the ID kernel on
 #   BASELINE config 2, and the HBM-traffic counters for the three bench shapes, batch-size sweeps, tail experiment, rollout.
 # Under rocprofv3 the program itself follows `--` (python3 <script>): no env / bash -c / launcher hop.
-tag=${1:-r05}; out=gpurun_out/$tag; mkdir -p $out; root=$PWD
+tag=${1:-r06}; out=gpurun_out/$tag; mkdir -p $out; root=$PWD
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1
 python bench.py > $out/bench.json 2> $out/bench.err
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $root/$out/stats -o run --output-format csv -- python3 $root/bench.py --no-cpu-baseline --steps 200 > $root/$out/stats.log 2>&1 )
