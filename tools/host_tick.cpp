@@ -307,6 +307,10 @@ struct HexHost {
   int wave_max_int(int x) { return x; }
 };
 
+// warm start of the emulated rollout (host_hex_rollout): the per-lane seed bit of hex_gi<..., WARM> between the ticks of ONE robot
+static int g_hex_warm = 0;
+static bool g_hex_seed[16];
+
 extern "C" int host_hex_batch(int kind, const double* flat215, const double* params12, const int* q_perm,
                               const int* act_perm, int n, int stride, const double* q, const double* v,
                               const double* tg, const unsigned char* mask, const double* mu,
@@ -346,10 +350,23 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
     const bool tb = P.tau_max < 1e300;
 #define HEX_RUN(K) (tb ? wbc::hex_tick<HexHost, K, true>(m, P, qo, in, a.mask[i] & 0xFu, mui, msi, pk[h], ot, om, &it) \
                        : wbc::hex_tick<HexHost, K, false>(m, P, qo, in, a.mask[i] & 0xFu, mui, msi, pk[h], ot, om, &it))
-    if (a.kind == wbc::KIND_ID) st = HEX_RUN(wbc::KIND_ID);
-    else if (a.kind == wbc::KIND_PC) st = HEX_RUN(wbc::KIND_PC);
-    else if (a.kind == wbc::KIND_CLF) st = HEX_RUN(wbc::KIND_CLF);
-    else st = HEX_RUN(wbc::KIND_MPTC);
+    if (!g_hex_warm) {
+      if (a.kind == wbc::KIND_ID) st = HEX_RUN(wbc::KIND_ID);
+      else if (a.kind == wbc::KIND_PC) st = HEX_RUN(wbc::KIND_PC);
+      else if (a.kind == wbc::KIND_CLF) st = HEX_RUN(wbc::KIND_CLF);
+      else st = HEX_RUN(wbc::KIND_MPTC);
+    } else {
+      // the rollout kernels' instantiation (WARM): this lane's friction row was active when the robot's previous tick ended
+      bool sd = g_hex_seed[h];
+#define HEX_RUN_W(K) (tb ? wbc::hex_tick<HexHost, K, true, true>(m, P, qo, in, a.mask[i] & 0xFu, mui, msi, pk[h], ot, om, &it, &sd) \
+                         : wbc::hex_tick<HexHost, K, false, true>(m, P, qo, in, a.mask[i] & 0xFu, mui, msi, pk[h], ot, om, &it, &sd))
+      if (a.kind == wbc::KIND_ID) st = HEX_RUN_W(wbc::KIND_ID);
+      else if (a.kind == wbc::KIND_PC) st = HEX_RUN_W(wbc::KIND_PC);
+      else if (a.kind == wbc::KIND_CLF) st = HEX_RUN_W(wbc::KIND_CLF);
+      else st = HEX_RUN_W(wbc::KIND_MPTC);
+#undef HEX_RUN_W
+      g_hex_seed[h] = (st == wbc::ST_OK) && sd;
+    }
 #undef HEX_RUN
     if (h == 0) { if (a.status) a.status[i] = st; if (a.iters) a.iters[i] = it; }
   };
@@ -375,6 +392,60 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
 // ---------------------------------------------------------------------------------------------
 // Host instantiation of the hinted nearest-sample search of the persistent rollout (wbc_traj_dev.hpp).
 #include "../quadruped_drake_amd/csrc/wbc_traj_dev.hpp"
+// Closed loop on the host emulation (tests): `steps` ticks of  targets[step] -> 16-lane tick -> semi-implicit Euler (the arithmetic of
+// wbc_integrate_kernel / wbc_hex_rollout_kernel) for n robots, one after the other; every robot sees the same target sequence tg_seq[steps][54] and
+// masks[steps].  warm != 0: every tick after a robot's first starts its active set from the previous tick's (hex_gi<..., WARM>), as
+// wbc_set_warm_start makes the device's rollout kernels do.  q, v: in/out; tau, met, status: the last tick's; iters_sum[n]: active-set trips per robot.
+extern "C" int host_hex_rollout(int kind, const double* flat215, const double* params12, int n, int stride, int steps, double dt, int warm,
+                                double* q, double* v, const double* tg_seq, const unsigned char* masks, const double* mu, const double* mass_scale,
+                                double* tau, double* met, int* status, double* iters_sum, int* status_nonzero_ticks) {
+  double* const sink = g_vdot;
+  int bad_total = 0;
+  for (int i = 0; i < n; i++) {
+    double q1[19], v1[18], vd1[18], tau1[12], met1[4];
+    for (int r = 0; r < 19; r++) q1[r] = q[(size_t)r * stride + i];
+    for (int r = 0; r < 18; r++) v1[r] = v[(size_t)r * stride + i];
+    for (int h = 0; h < 16; h++) g_hex_seed[h] = false;
+    int st1 = 0;
+    double its = 0.0;
+    for (int s = 0; s < steps; s++) {
+      int it1 = 0;
+      for (int r = 0; r < 18; r++) vd1[r] = 0.0;
+      g_vdot = vd1;
+      g_hex_warm = warm;
+      const int rc = host_hex_batch(kind, flat215, params12, nullptr, nullptr, 1, 1, q1, v1, tg_seq + (size_t)s * 54, masks + s, mu ? mu + i : nullptr,
+                                    mass_scale ? mass_scale + i : nullptr, tau1, met1, &st1, &it1);
+      g_hex_warm = 0;
+      g_vdot = sink;
+      if (rc) return rc;
+      its += it1;
+      bad_total += (st1 != 0);
+      // v+ = v + dt vd ; quat+ = exp(dt/2 w+) (x) quat, renormalised ; p, joints advance with v+
+      double vn[18];
+      for (int r = 0; r < 18; r++) { vn[r] = v1[r] + dt * vd1[r]; v1[r] = vn[r]; }
+      const double wn = sqrt(vn[0] * vn[0] + vn[1] * vn[1] + vn[2] * vn[2]);
+      const double ang = 0.5 * wn * dt;
+      double dw = 1.0, dx = 0.0, dy = 0.0, dz = 0.0;
+      if (wn > 0.0) { const double sc = sin(ang) / wn; dw = cos(ang); dx = sc * vn[0]; dy = sc * vn[1]; dz = sc * vn[2]; }
+      const double w1 = q1[0], x1 = q1[1], y1 = q1[2], z1 = q1[3];
+      const double qw = dw * w1 - dx * x1 - dy * y1 - dz * z1, qx = dw * x1 + dx * w1 + dy * z1 - dz * y1;
+      const double qy = dw * y1 - dx * z1 + dy * w1 + dz * x1, qz = dw * z1 + dx * y1 - dy * x1 + dz * w1;
+      const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+      q1[0] = qw * inv; q1[1] = qx * inv; q1[2] = qy * inv; q1[3] = qz * inv;
+      for (int r = 0; r < 3; r++) q1[4 + r] += dt * vn[3 + r];
+      for (int r = 0; r < 12; r++) q1[7 + r] += dt * vn[6 + r];
+    }
+    for (int r = 0; r < 19; r++) q[(size_t)r * stride + i] = q1[r];
+    for (int r = 0; r < 18; r++) v[(size_t)r * stride + i] = v1[r];
+    for (int r = 0; r < 12; r++) tau[(size_t)r * stride + i] = tau1[r];
+    if (met) for (int r = 0; r < 4; r++) met[(size_t)r * stride + i] = met1[r];
+    if (status) status[i] = st1;
+    if (iters_sum) iters_sum[i] = its;
+  }
+  if (status_nonzero_ticks) *status_nonzero_ticks = bad_total;
+  return 0;
+}
+
 extern "C" int host_traj_index(const double* ts, int K, double wait_time, double t, int hint) {
   wbc::TrajDev T{K, wait_time, ts, nullptr, nullptr, nullptr, 0};
   return wbc::traj_index(T, t, hint);
