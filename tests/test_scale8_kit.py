@@ -104,3 +104,21 @@ def test_one_gpu_runs_of_both_hosts_pass_the_checker(tmp_path):
         files.append(str(h))
     ok, rows = s8.check(files)
     assert ok, rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_real_multi_rank_runs_sharing_one_gpu_match_the_predictions(world, tmp_path):
+    """The nearest thing to an N-GPU run this pool allows: `bench.py --gpus N` self-launches N REAL rank processes -- each generates its own window of the
+    sharded config-5 batch, steps it with the real kernels, joins the ONE statistics all-gather -- all on GPU 0 (`--share-gpu --backend gloo`: RCCL refuses
+    two ranks on one device, so the collective is gloo's; sharding, windows, launcher, statistics and the MAX over ranks are the N-GPU run's own).  Every
+    rank's torque checksum and the gathered statistics must be the ones profiles/scale8_expected.json predicts for that N."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--config", "5", "--per-gpu", "4096", "--backend", "gloo", "--share-gpu",
+                        "--steps", "10", "--warmup", "2", "--ramp-seconds", "0", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    f = tmp_path / ("bench_%d.json" % world); f.write_text(r.stdout)
+    ok, rows = s8.check([str(f)])
+    assert ok, rows
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == world == d["ranks_seen"] and len(set(d["per_rank_tau_fnv1a64"])) == world and d["status_nonzero"] == 0

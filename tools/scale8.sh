@@ -2,6 +2,8 @@
 # 8-GPU hand-over kit, part 2: ONE command for a person with a multi-GPU MI355X node.
 #
 #   tools/scale8.sh [outdir]            (from the repository root; default outdir profiles/scale8)
+#   tools/scale8.sh outdir --share-one-gpu     a ONE-GPU box: N = 2, 4, 8 REAL rank processes of bench.py sharing GPU 0 (gloo instead of RCCL: RCCL
+#                                              refuses two ranks on one device); sharding, windows, launcher and statistics are the N-GPU run's own
 #
 # Builds everything, then for N in 1 2 4 8 (as many as the node has) steps the sharded BASELINE configs[4] batch (4096 instances per GPU) through
 #   * bench.py --gpus N          one process per GPU (torch.distributed over RCCL only for the end-of-rollout statistics), and
@@ -12,6 +14,7 @@
 set -u
 cd "$(dirname "$0")/.."
 out=${1:-profiles/scale8}
+share=${2:-}
 mkdir -p "$out"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 python3 -c "import __graft_entry__ as g; g.build()" > "$out/build.log" 2>&1 || { echo "build failed: $out/build.log"; exit 1; }
@@ -19,6 +22,11 @@ ngpu=$(python3 -c "import torch; print(torch.cuda.device_count())")
 echo "GPUs visible: $ngpu"
 files=()
 for n in 1 2 4 8; do
+  if [ "$share" = "--share-one-gpu" ] && [ "$n" -gt "$ngpu" ]; then
+    python3 bench.py --gpus $n --config 5 --per-gpu 4096 --backend gloo --share-gpu --steps 50 --warmup 5 --no-cpu-baseline > "$out/bench_shared_$n.json" 2> "$out/bench_shared_$n.err" \
+      && files+=("$out/bench_shared_$n.json") || echo "bench.py --gpus $n --share-gpu FAILED: $out/bench_shared_$n.err"
+    continue
+  fi
   [ "$n" -le "$ngpu" ] || { echo "N=$n skipped: only $ngpu GPU(s)"; continue; }
   # bench.py launches its own ranks for N > 1 (python -m torch.distributed.run --nproc-per-node N ... on 127.0.0.1)
   python3 bench.py --gpus $n --config 5 --per-gpu 4096 --steps 200 --warmup 20 --no-cpu-baseline > "$out/bench_$n.json" 2> "$out/bench_$n.err" \
