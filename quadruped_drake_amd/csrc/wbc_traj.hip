@@ -43,11 +43,24 @@ inline const uint8_t* rd3(const uint8_t* p, double* out) {
 }
 
 // One thread per robot: nearest sample (wbc_traj_dev.hpp), then a 54-double gather.
+// The search is a chain of DEPENDENT loads (each a trip to L2 or HBM, ~1 us when the table is cold): from the middle of a 5001-sample table it is 13 of
+// them and the whole kernel 13.5 us.  traj_index starts from any hint and gallops, so the thread first guesses where its time falls if the samples were
+// evenly spaced (two loads every thread shares: the first and the last timestamp); a stored trajectory is evenly spaced or nearly so (planners/towr.py
+// streams TOWR's fixed 1 ms grid), the guess is then the answer or next to it, and an unevenly spaced table only costs the gallop it always cost.  The hint
+// changes how the index is found, never which (round 6).
 __global__ void traj_lookup_kernel(int n, int ld, wbc::TrajDev T, const double* __restrict__ time,
                                    double* __restrict__ targets, uint8_t* __restrict__ contact_mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int c = wbc::traj_index(T, time[i], T.K / 2);
+  const double ti = time[i];
+  int hint = T.K / 2;
+  if (T.K > 1) {
+    const double t0 = T.ts[0], t1 = T.ts[T.K - 1], x = (ti - T.wait_time - t0) * (double)(T.K - 1);
+    // (a NaN or out-of-range guess is clamped inside traj_index; a zero span keeps the middle)
+    if (t1 > t0 && x > 0.0) { const double g = x / (t1 - t0); hint = (g < (double)(T.K - 1)) ? (int)(g + 0.5) : T.K - 1; }
+    else if (t1 > t0) hint = 0;
+  }
+  const int c = wbc::traj_index(T, ti, hint);
   const double* src = c < 0 ? T.standing : T.table + (size_t)c * 54;
   const uint8_t mk = c < 0 ? T.standing_mask : T.masks[c];
   for (int r = 0; r < 54; r++) targets[(size_t)r * ld + i] = src[r];
@@ -283,7 +296,8 @@ int wbc_traj_lookup(wbc_traj t, void* hip_stream, int n, int ld, const double* t
   if (n == 0) return 0;
   WBC_ON_DEVICE(t->device, tfail);
   wbc::TrajDev T{t->K, t->wait_time, t->d_ts, t->d_table, t->d_masks, t->d_standing, t->standing_mask};
-  hipLaunchKernelGGL(traj_lookup_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)hip_stream, n, ld, T, time,
+  // 64-thread workgroups: a batch of 4096 robots spreads over 64 compute units instead of 16 (the kernel is a latency chain, not a throughput problem)
+  hipLaunchKernelGGL(traj_lookup_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, n, ld, T, time,
                      targets, contact_mask);
   HIP_TRY(hipGetLastError());
   return 0;
