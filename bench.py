@@ -307,6 +307,30 @@ def closed_loop(shard, device, steps=300):
     stand = TrunkTrajectory(np.zeros(0), np.zeros((0, 54)), np.zeros(0, np.uint8), wait_time=1e9, device=device,
                             standing_targets=st_t, standing_mask=0b1111, model=shard["model"])
     out["standing"] = run(stand, q0, v0, np.zeros(n))
+    # a closed loop that sits on its friction limits (body target swaying sideways at 7.9 m/s^2 against mu g = 6.9), cold and with the warm-started
+    # active set of wbc_set_warm_start (profiles/r06/warm_start.md): 100 ticks each from the same start -- informational like the rest of this object
+    dur = 0.4
+    tss = np.arange(int(round(dur / dt)) + 1) * dt
+    tgs = workloads.standing_targets(shard["model"], tss.size)
+    w = 2 * np.pi * 2.0
+    tgs[1] += 0.05 * np.sin(w * tss); tgs[4] = 0.05 * w * np.cos(w * tss); tgs[7] = -0.05 * w * w * np.sin(w * tss)
+    sway = TrunkTrajectory(tss, np.ascontiguousarray(tgs.T), np.full(tss.size, 0b1111, np.uint8), wait_time=0.0, device=device, model=shard["model"])
+    t0s = np.random.default_rng(5).uniform(0.0, 0.2, n)
+    sat = {}
+    for name, warm in (("cold", False), ("warm_start", True)):
+        ctrl = cls(model=shard["model"], max_batch=n, device=device)
+        ctrl.set_warm_start(warm)
+        q = torch.tensor(q0, device=dev); v = torch.tensor(v0, device=dev); t = torch.tensor(t0s, device=dev)
+        ctrl.rollout(sway, 1, dt, q.clone(), v.clone(), t.clone()); ctrl.sync()
+        ctrl.stats(reset=True)
+        ta = time.perf_counter()
+        ctrl.rollout(sway, 100, dt, q, v, t); ctrl.sync()
+        el = time.perf_counter() - ta
+        s = ctrl.stats()
+        ctrl.close()
+        sat[name] = {"us_per_step": el / 100 * 1e6, "iters_per_tick": s["iters_sum"] / max(1.0, s["ticks"]), "status_nonzero": s["status_nonzero"]}
+    sat["scenario"] = "sideways sway at 2 Hz, 5 cm (saturated part of every period), 100 closed-loop ticks, dt %g; warm_start = wbc_set_warm_start(1), off by default" % dt
+    out["saturated"] = sat
     return out
 
 
