@@ -276,8 +276,11 @@ def test_evaluation_after_a_drop_and_graded_pivots_on_host(tmp_path):
         assert rc == 0 and (st == 0).all()
         return tau
 
-    plain = build(["-DWBC_NO_DROP_REFINE", "-DWBC_NATURAL_PIVOTS"], "libhost_r3.so")
-    norefine = build(["-DWBC_NO_DROP_REFINE"], "libhost_norefine.so")
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(2) as ex:                          # the two compiles side by side
+        fa = ex.submit(build, ["-DWBC_NO_DROP_REFINE", "-DWBC_NATURAL_PIVOTS"], "libhost_r3.so")
+        fb = ex.submit(build, ["-DWBC_NO_DROP_REFINE"], "libhost_norefine.so")
+        plain, norefine = fa.result(), fb.result()
     b = workloads.make_batch(2, n=768, seed=50002)
     tau_l, _, st_l = old.step_batch("id", old.model(b["model"]), old.params("id"), b["q"], b["v"], b["targets"], b["mask"])
     assert (st_l == 0).all()
@@ -478,11 +481,14 @@ def test_no_unwritten_storage_feeds_the_arithmetic(tmp_path):
     clang = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(clang):
         pytest.skip("no clang++ for -ftrivial-auto-var-init=pattern")
-    libs = []
-    for name, extra in (("plain", []), ("poison", ["-ftrivial-auto-var-init=pattern"])):
+    builds = []
+    for name, extra in (("plain", []), ("poison", ["-ftrivial-auto-var-init=pattern"])):      # the two compiles side by side
         so = str(tmp_path / ("libhost_tick_%s.so" % name))
-        subprocess.check_call([clang, "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off"] + extra +
-                              ["-o", so, os.path.join(root, "tools", "host_tick.cpp")])
+        builds.append((so, subprocess.Popen([clang, "-O2", "-std=c++20", "-pthread", "-fPIC", "-shared", "-ffp-contract=off", "-DHOST_TICK_HEX_ONLY"] + extra +
+                                            ["-o", so, os.path.join(root, "tools", "host_tick.cpp")])))
+    libs = []
+    for so, proc in builds:
+        assert proc.wait() == 0
         libs.append(C.CDLL(so))
     dp = C.POINTER(C.c_double)
     names = ("Kp_body_p", "Kd_body_p", "Kp_body_rpy", "Kd_body_rpy", "Kp_foot", "Kd_foot", "w_body", "w_foot", "mu", "Kd_contact", "tau_max", "tiebreak_eps2")

@@ -59,6 +59,7 @@ static int run_one(int kind, const wbc::ModelC& m, const wbc::ParamsC& P, int i,
   return wbc::tick<T, wbc::KIND_MPTC>(m, P, in, mask, T(mu), T(ms), ot, om, iters);
 }
 
+#ifndef HOST_TICK_HEX_ONLY   // (the variant builds of tests/host_tick.py::build_variant only call host_hex_batch: a third of the compile time)
 extern "C" {
 
 // params12: Kp_body_p, Kd_body_p, Kp_body_rpy, Kd_body_rpy, Kp_foot, Kd_foot, w_body, w_foot, mu,
@@ -152,6 +153,8 @@ int host_tick_count(int kind, const double* flat215, const double* params12, int
   return 0;
 }
 }
+
+#endif   // HOST_TICK_HEX_ONLY
 
 #include <vector>
 
@@ -356,6 +359,7 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
       else if (a.kind == wbc::KIND_CLF) st = HEX_RUN(wbc::KIND_CLF);
       else st = HEX_RUN(wbc::KIND_MPTC);
     } else {
+#ifndef HOST_TICK_HEX_ONLY
       // the rollout kernels' instantiation (WARM): this lane's friction row was active when the robot's previous tick ended
       bool sd = g_hex_seed[h];
 #define HEX_RUN_W(K) (tb ? wbc::hex_tick<HexHost, K, true, true>(m, P, qo, in, a.mask[i] & 0xFu, mui, msi, pk[h], ot, om, &it, &sd) \
@@ -366,6 +370,9 @@ extern "C" int host_hex_batch(int kind, const double* flat215, const double* par
       else st = HEX_RUN_W(wbc::KIND_MPTC);
 #undef HEX_RUN_W
       g_hex_seed[h] = (st == wbc::ST_OK) && sd;
+#else
+      st = wbc::ST_SINGULAR;   // (not part of a HOST_TICK_HEX_ONLY build)
+#endif
     }
 #undef HEX_RUN
     if (h == 0) { if (a.status) a.status[i] = st; if (a.iters) a.iters[i] = it; }
