@@ -55,7 +55,7 @@ class IllConditionedWarning(RuntimeWarning):
     """A tick of a task-space law with |sin(knee)| < 1e-4 on a leg (status 3): torques computed, not vouched for."""
 
 
-STATUS_TEXT = {1: "iteration cap", 2: "singular / infeasible: torques and accelerations are zero",
+STATUS_TEXT = {1: "iteration cap", 2: "not answerable -- singular, infeasible, or a malformed instance (a non-finite input, a bad mu / mass scale, an overflow): torques, accelerations and metrics are zero",
                3: "ill-conditioned: |sin(knee)| < 1e-4 on a leg under a task-space law; torques written but not trustworthy"}
 
 

@@ -226,3 +226,26 @@ def test_rollout_with_malformed_instances(kind, box):
     hits = out["stats"]["status_nonzero"] - ref["stats"]["status_nonzero"]
     assert crossing.sum() <= hits <= 2 * crossing.sum(), hits       # every crossing robot was reported at the tick(s) nearest to the sample, and only then
     assert not np.array_equal(out["q"][:, crossing], ref["q"][:, crossing])     # (they lost a tick of control: their trajectories differ, finitely)
+
+
+def test_single_robot_mirror_raises_on_a_malformed_state():
+    """N = 1 through the Python mirror of the reference's interface (ControlLaw): where the reference would assert -- or hand NaN torques to the plant -- the mirror
+    raises SolverError with status 2 and zero torques riding along, for both handle kinds (device pointers; the host-pointer handle of the LeafSystem adapter)."""
+    from quadruped_drake_amd import MPTCController, SolverError, workloads
+    b = workloads.make_batch(3, n=1)
+    d = {}
+    for i, f in enumerate(("lf", "rf", "lh", "rh")):
+        d["p_" + f] = b["targets"][18 + 9 * i:21 + 9 * i, 0]; d["pd_" + f] = np.zeros(3); d["pdd_" + f] = np.zeros(3)
+    d.update(rpy_body=np.zeros(3), p_body=b["targets"][0:3, 0], rpyd_body=np.zeros(3), pd_body=np.zeros(3), rpydd_body=np.zeros(3), pdd_body=np.zeros(3),
+             contact_states=[True, False, False, True])
+    for host_ptrs in (False, True):
+        c = MPTCController(max_batch=1, device=0, host_ptrs=host_ptrs)
+        u = c.ControlLaw(b["q"][:, 0], b["v"][:, 0], d)
+        assert c.last_status == 0 and np.isfinite(u).all() and np.abs(u).max() > 0
+        q = b["q"][:, 0].copy(); q[9] = np.nan
+        with pytest.raises(SolverError) as ei:
+            c.ControlLaw(q, b["v"][:, 0], d)
+        assert ei.value.args[1] == 2 and "malformed" in ei.value.args[0] and (ei.value.args[2] == 0).all()
+        u2 = c.ControlLaw(b["q"][:, 0], b["v"][:, 0], d)              # the handle is as good as before
+        assert np.array_equal(u2, u)
+        c.close()
