@@ -122,3 +122,43 @@ def test_bench_one_gpu_through_the_process_group_branch():
     assert abs(parts - reg["total"]) < 1.0 and reg["device_time_of_the_K_launches"] < reg["total"]
     assert abs(d["ms_per_step"] * 1e3 * 10 - reg["total"]) < 1.0
     assert abs(d["value_kernel_only"] - 4096.0 / (d["roofline"]["kernel_ms"] * 1e-3)) < 1e-6 * d["value_kernel_only"] and d["value_kernel_only"] > d["value"]
+
+
+def _torchrun(nproc, args, timeout=600):
+    """The driver's own launch line for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ..."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_the_drivers_torchrun_line_world2_gloo_dry_run():
+    """bench.py under the launcher the driver uses (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from torch.distributed.run, not from bench.py's own
+    self-launch): two ranks, contiguous shards, one statistics exchange, ONE JSON line from rank 0."""
+    r = _torchrun(2, ["--gpus", "2", "--backend", "gloo", "--dry-run", "--steps", "3", "--warmup", "1", "--per-gpu", "64"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["per_rank_ticks"] == [64.0 * 3, 64.0 * 3]
+
+
+@pytest.mark.gpu
+def test_the_drivers_torchrun_line_two_real_ranks_sharing_the_gpu():
+    """The same launcher with the REAL kernels: two ranks on GPU 0 (gloo stands in for RCCL, which needs a device per rank), the config-5 shards of the
+    8-GPU hand-over kit -- the line must match profiles/scale8_expected.json like a self-launched run does."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scale8_expected as s8
+    r = _torchrun(2, ["--gpus", "2", "--config", "5", "--per-gpu", "4096", "--backend", "gloo", "--share-gpu", "--steps", "10", "--warmup", "2",
+                      "--ramp-seconds", "0", "--no-cpu-baseline"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        f.write(r.stdout)
+    ok, rows = s8.check([f.name])
+    os.unlink(f.name)
+    assert ok, rows
