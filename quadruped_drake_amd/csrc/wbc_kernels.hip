@@ -599,15 +599,19 @@ wbc_hex_rollout_kernel(const wbc::ModelC* __restrict__ mp, const wbc::ParamsX* _
 
 // ---------------------------------------------------------------- forward step
 // Semi-implicit Euler in the reference's coordinates: v = [w_WB (world); v_WBo (world); qd].
-__global__ void wbc_integrate_kernel(int n, int ld, double dt, double* __restrict__ q, double* __restrict__ v,
+__global__ void __launch_bounds__(64) wbc_integrate_kernel(int n, int ld, double dt, double* __restrict__ q, double* __restrict__ v,
                                      const double* __restrict__ vd) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  double vn[18];
-  for (int r = 0; r < 18; r++) {
-    vn[r] = v[(size_t)r * ld + i] + dt * vd[(size_t)r * ld + i];
-    v[(size_t)r * ld + i] = vn[r];
-  }
+  // EVERY load first: the rows of q are read and written through one pointer with a run-time stride, so the compiler cannot move a load of q above a
+  // store to q -- written row by row the kernel was three dependent trips to memory (v | quaternion | the 15 other rows of q); this way it is one
+  double vn[18], qq[19];
+#pragma unroll
+  for (int r = 0; r < 18; r++) vn[r] = v[(size_t)r * ld + i];
+#pragma unroll
+  for (int r = 0; r < 19; r++) qq[r] = q[(size_t)r * ld + i];
+#pragma unroll
+  for (int r = 0; r < 18; r++) vn[r] = vn[r] + dt * vd[(size_t)r * ld + i];
   // orientation: q+ = exp(dt/2 w) (x) q, w in the world frame
   const double wn = sqrt(vn[0] * vn[0] + vn[1] * vn[1] + vn[2] * vn[2]);
   const double ang = 0.5 * wn * dt;
@@ -616,15 +620,21 @@ __global__ void wbc_integrate_kernel(int n, int ld, double dt, double* __restric
     const double sc = sin(ang) / wn;
     dw = cos(ang); dx = sc * vn[0]; dy = sc * vn[1]; dz = sc * vn[2];
   }
-  const double w1 = q[i], x1 = q[(size_t)ld + i], y1 = q[(size_t)2 * ld + i], z1 = q[(size_t)3 * ld + i];
+  const double w1 = qq[0], x1 = qq[1], y1 = qq[2], z1 = qq[3];
   double qw = dw * w1 - dx * x1 - dy * y1 - dz * z1;
   double qx = dw * x1 + dx * w1 + dy * z1 - dz * y1;
   double qy = dw * y1 - dx * z1 + dy * w1 + dz * x1;
   double qz = dw * z1 + dx * y1 - dy * x1 + dz * w1;
   const double inv = 1.0 / sqrt(qw * qw + qx * qx + qy * qy + qz * qz);
-  q[i] = qw * inv; q[(size_t)ld + i] = qx * inv; q[(size_t)2 * ld + i] = qy * inv; q[(size_t)3 * ld + i] = qz * inv;
-  for (int r = 0; r < 3; r++) q[(size_t)(4 + r) * ld + i] += dt * vn[3 + r];
-  for (int r = 0; r < 12; r++) q[(size_t)(7 + r) * ld + i] += dt * vn[6 + r];
+  qq[0] = qw * inv; qq[1] = qx * inv; qq[2] = qy * inv; qq[3] = qz * inv;
+#pragma unroll
+  for (int r = 0; r < 3; r++) qq[4 + r] += dt * vn[3 + r];
+#pragma unroll
+  for (int r = 0; r < 12; r++) qq[7 + r] += dt * vn[6 + r];
+#pragma unroll
+  for (int r = 0; r < 18; r++) v[(size_t)r * ld + i] = vn[r];
+#pragma unroll
+  for (int r = 0; r < 19; r++) q[(size_t)r * ld + i] = qq[r];
 }
 
 // out <- sum / max over all slots: one 256-thread block per statistics word, coalesced reads (word-major slots)
@@ -1050,7 +1060,7 @@ int wbc_integrate(wbc_handle h, int n, int ld, double dt, double* q, double* v, 
   if (h->flags & WBC_HOST_PTRS) return misuse("wbc_integrate: needs a WBC_DEVICE_PTRS handle");
   if (n == 0) return 0;
   WBC_ON_DEVICE(h->device, fail);
-  hipLaunchKernelGGL(wbc_integrate_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, n, ld, dt, q, v, vdot);
+  hipLaunchKernelGGL(wbc_integrate_kernel, dim3((n + 63) / 64), dim3(64), 0, h->stream, n, ld, dt, q, v, vdot);   // (64-thread workgroups: 64 compute units at N = 4096)
   HIP_TRY(hipGetLastError());
   return 0;
 }
